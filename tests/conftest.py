@@ -1,0 +1,44 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "audio-visual-vad_amd")
+for p in (ROOT, PKG, os.path.dirname(os.path.abspath(__file__))):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by `pytest -m gpu` on the GPU box)")
+
+
+def pytest_collection_modifyitems(config, items):
+    if torch.cuda.is_available():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+@pytest.fixture
+def golden():
+    return load_golden
+
+
+def wn_cfg_from(g):
+    fw, qc, R, D, Bn, P, ub = [int(v) for v in g["cfg_scalars"]]
+    return dict(filter_width=fw, quantization_channel=qc, dilations=[int(d) for d in g["cfg_dilations"]],
+                en_residual_channel=R, en_dilation_channel=D, en_bottleneck_width=Bn,
+                en_pool_kernel_size=P, use_bias=bool(ub))
