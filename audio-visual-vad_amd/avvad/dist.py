@@ -1,0 +1,107 @@
+"""Data-parallel gradient exchange: one process per GPU, bucketed all-reduce (SUM) of the flat gradient
+buffer over RCCL/xGMI, launched as soon as a bucket's last gradient has been accumulated so the exchange
+overlaps the rest of backward.
+
+Replaces ``nn.parallel.DataParallel(model, device_ids=[0,1,2,3])`` (``scripts/train_AV_net.py:193``), which
+broadcasts all parameters and reduces all gradients through GPU 0 every step.  The loss is a SUM over
+sequences (``train_AV_net.py:298-302``), so a SUM all-reduce (no division by world size) reproduces the
+single-process gradient of the global batch; BatchNorm statistics stay per replica, as under DataParallel.
+
+The reducer only needs ``torch.distributed`` and flat views, so it runs unchanged on the gloo backend with
+CPU tensors -- that is how the N>1 path is tested without GPUs."""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* from the launcher (torch.distributed.run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_batch(tensors, rank, world):
+    """Even split of the global batch on dim 0 (what DataParallel.scatter does)."""
+    out = []
+    for t in tensors:
+        n = t.shape[0]
+        if n % world:
+            raise ValueError("global batch %d not divisible by world size %d" % (n, world))
+        k = n // world
+        out.append(t[rank * k:(rank + 1) * k])
+    return out
+
+
+def flat_views(params):
+    """Re-home ``.grad`` of every trainable parameter into one flat buffer (CPU or GPU);
+    returns (flat_grad, offsets).  FlatAdam does the same for GPU training."""
+    params = [p for p in params if p.requires_grad]
+    offsets = [0]
+    for p in params:
+        offsets.append(offsets[-1] + (p.numel() + 63) // 64 * 64)
+    flat = torch.zeros(offsets[-1], dtype=params[0].dtype, device=params[0].device)
+    for p, o in zip(params, offsets):
+        p.grad = flat[o:o + p.numel()].view(p.shape)
+    return flat, offsets
+
+
+class BucketReducer:
+    """params: trainable parameters whose ``.grad`` are views into ``flat_grad`` at ``offsets`` (elements).
+    Buckets are contiguous ranges of the flat buffer of about ``bucket_bytes`` (xGMI is point-to-point:
+    few large messages beat many small ones; 25 MB keeps a ring step well above the latency floor)."""
+
+    def __init__(self, params, flat_grad, offsets, bucket_bytes=25 << 20, group=None):
+        self.flat_grad = flat_grad
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.buckets = []          # (start, end, n_params)
+        self.param_bucket = {}
+        start, count = 0, 0
+        for i, p in enumerate(params):
+            end = offsets[i + 1]
+            count += 1
+            self.param_bucket[id(p)] = len(self.buckets)
+            if (end - start) * 4 >= bucket_bytes or i == len(params) - 1:
+                self.buckets.append((start, end, count))
+                start, count = end, 0
+        self.pending = [0] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)
+        self.handles = []
+        self._hooks = []
+        if self.world > 1:
+            for p in params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+
+    def _on_grad(self, p):
+        b = self.param_bucket[id(p)]
+        self.pending[b] += 1
+        if self.pending[b] == self.buckets[b][2]:
+            self._launch(b)
+
+    def _launch(self, b):
+        if self.launched[b]:
+            return
+        s, e, _ = self.buckets[b]
+        self.launched[b] = True
+        self.handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Call after backward: launches whatever did not fire (parameters without a gradient this step)
+        and waits for every bucket."""
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                self._launch(b)
+            for h in self.handles:
+                h.wait()
+        self.handles = []
+        self.pending = [0] * len(self.buckets)
+        self.launched = [False] * len(self.buckets)

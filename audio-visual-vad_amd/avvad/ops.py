@@ -1,0 +1,327 @@
+"""torch.autograd wrappers around the C ABI of libavvad_hip.so.
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd tape;
+every arithmetic step of the hot path runs in the HIP kernels.  All tensors
+must be fp32, contiguous and live on the GPU -- anything else raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _dev(t, name):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise L.AvvadError("%s must be a GPU tensor: the AV-VAD hot path has no CPU fallback "
+                           "(use the oracle/ package for CPU checks)" % name)
+    if t.dtype != torch.float32:
+        raise L.AvvadError("%s must be float32, got %s" % (name, t.dtype))
+    return t.contiguous()
+
+
+def _ws(nbytes, device):
+    if nbytes == 0:
+        raise L.AvvadError("workspace query failed (bad descriptor)")
+    return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+
+
+def lengths_i32(lengths, device):
+    """`lengths` arrives as a LongTensor (train loop) or a Python list (eval)."""
+    if isinstance(lengths, torch.Tensor):
+        return lengths.to(device=device, dtype=torch.int32).contiguous()
+    return torch.tensor([int(v) for v in lengths], dtype=torch.int32, device=device)
+
+
+# --------------------------------------------------------------------------- GEMM / Linear
+def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, accumulate=False, split_k=1):
+    d = L.GemmDesc(M, N, K, lda, ldb, ldc, int(transA), int(transB), int(accumulate), split_k, 0, 0)
+    L.check(L.lib().avvad_gemm_f32(L.ptr(A), L.ptr(B), L.ptr(bias), L.ptr(C_out), C.byref(d), _stream()), "avvad_gemm_f32")
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b   (nn.Linear: Audio_Net.py:59, Video_Net.py:116, AV_Net.py:140)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x2 = _dev(x, "x").view(-1, x.shape[-1])
+        w = _dev(weight, "weight")
+        rows, K = x2.shape
+        N = w.shape[0]
+        y = torch.empty(rows, N, dtype=torch.float32, device=x.device)
+        gemm(x2, w, y, rows, N, K, K, K, N, transB=True, bias=_dev(bias, "bias") if bias is not None else None)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias = bias is not None
+        return y.view(x.shape[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        rows, K = x2.shape
+        N = w.shape[0]
+        dy2 = _dev(dy, "dy").view(rows, N)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x2)
+            gemm(dy2, w, dx, rows, K, N, N, K, K)                       # [rows,N] x [N,K]
+            dx = dx.view(dy.shape[:-1] + (K,))
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros_like(w)
+            gemm(dy2, x2, dw, N, K, rows, N, K, K, transA=True, accumulate=True)   # dy^T x
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(N, dtype=torch.float32, device=dy.device)
+            L.check(L.lib().avvad_colsum_acc(L.ptr(dy2), rows, N, L.ptr(db), _stream()), "avvad_colsum_acc")
+        return dx, dw, db
+
+
+# --------------------------------------------------------------------------- LSTM layer
+class LstmLayerFn(torch.autograd.Function):
+    """One unidirectional LSTM layer over a padded batch with packed-sequence semantics."""
+
+    @staticmethod
+    def forward(ctx, x, lens32, w_ih, w_hh, b_ih, b_hh):
+        x = _dev(x, "x")
+        B, T, In = x.shape
+        H = w_hh.shape[1]
+        w_ih, w_hh, b_ih, b_hh = (_dev(t, n) for t, n in ((w_ih, "w_ih"), (w_hh, "w_hh"), (b_ih, "b_ih"), (b_hh, "b_hh")))
+        d = L.LstmDesc(B, T, In, H, lens32.data_ptr(), 1)
+        ws = _ws(L.lib().avvad_lstm_workspace(C.byref(d)), x.device)
+        y = torch.empty(B, T, H, dtype=torch.float32, device=x.device)
+        L.check(L.lib().avvad_lstm_layer_fwd(L.ptr(x), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), L.ptr(y),
+                                             C.byref(d), L.ptr(ws), ws.numel() * 4, _stream()), "avvad_lstm_layer_fwd")
+        ctx.save_for_backward(x, lens32, w_ih, w_hh, y, ws)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, lens32, w_ih, w_hh, y, ws = ctx.saved_tensors
+        B, T, In = x.shape
+        H = w_hh.shape[1]
+        dy = _dev(dy, "dy")
+        d = L.LstmDesc(B, T, In, H, lens32.data_ptr(), 1)
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        need_w = any(ctx.needs_input_grad[2:])
+        dw_ih = torch.zeros_like(w_ih) if need_w else None
+        dw_hh = torch.zeros_like(w_hh) if need_w else None
+        db_ih = torch.zeros(4 * H, dtype=torch.float32, device=x.device) if need_w else None
+        db_hh = torch.zeros(4 * H, dtype=torch.float32, device=x.device) if need_w else None
+        L.check(L.lib().avvad_lstm_layer_bwd(L.ptr(x), L.ptr(w_ih), L.ptr(w_hh), L.ptr(y), L.ptr(dy), L.ptr(dx),
+                                             L.ptr(dw_ih), L.ptr(dw_hh), L.ptr(db_ih), L.ptr(db_hh), C.byref(d),
+                                             L.ptr(ws), ws.numel() * 4, _stream()), "avvad_lstm_layer_bwd")
+        return dx, None, dw_ih, dw_hh, db_ih, db_hh
+
+
+def lstm_stack(x, lengths, lstm_module):
+    """Runs the parameters held by an ``nn.LSTM`` container through the HIP layers."""
+    if lstm_module.bidirectional or not lstm_module.bias or lstm_module.proj_size:
+        raise L.AvvadError("only the unidirectional, biased LSTM of the reference is supported")
+    lens32 = lengths_i32(lengths, x.device)
+    y = x
+    for l in range(lstm_module.num_layers):
+        y = LstmLayerFn.apply(y, lens32, getattr(lstm_module, "weight_ih_l%d" % l), getattr(lstm_module, "weight_hh_l%d" % l),
+                              getattr(lstm_module, "bias_ih_l%d" % l), getattr(lstm_module, "bias_hh_l%d" % l))
+    return y
+
+
+# --------------------------------------------------------------------------- WaveNet encoder
+class WavenetFn(torch.autograd.Function):
+    """wave (B,qc,L) -> (B,Bn,P).  params: causal_w, causal_b, bott_w, bott_b, then per layer
+    dil_w, dil_b, dense_w, dense_b (biases None when use_bias is False)."""
+
+    @staticmethod
+    def _desc(cfg, B, Lin, dil_arr, save):
+        return L.WavenetDesc(B, Lin, cfg["quantization_channel"], cfg["en_residual_channel"], cfg["en_dilation_channel"],
+                             cfg["en_bottleneck_width"], cfg["filter_width"], cfg["en_pool_kernel_size"],
+                             len(cfg["dilations"]), dil_arr, int(cfg["use_bias"]), int(save))
+
+    @staticmethod
+    def _ptrs(ts, n):
+        cw, cb, bw, bb = ts[:4]
+        rest = ts[4:]
+        arrs = [L.ptr_array(rest[k::4][:n]) for k in range(4)]
+        p = L.WavenetPtrs(L.ptr(cw), L.ptr(cb), arrs[0], arrs[1], arrs[2], arrs[3], L.ptr(bw), L.ptr(bb))
+        return p, arrs  # keep arrs alive
+
+    @staticmethod
+    def forward(ctx, wave, cfg, *params):
+        wave = _dev(wave, "wave")
+        B, qc, Lin = wave.shape
+        n = len(cfg["dilations"])
+        if qc != cfg["quantization_channel"] or len(params) != 4 + 4 * n:
+            raise L.AvvadError("wavenet: bad input channels / parameter list")
+        params = tuple(None if t is None else _dev(t, "param") for t in params)
+        dil_arr = (C.c_int * max(1, n))(*cfg["dilations"])
+        save = any(ctx.needs_input_grad)
+        d = WavenetFn._desc(cfg, B, Lin, dil_arr, save)
+        ws = _ws(L.lib().avvad_wavenet_workspace(C.byref(d)), wave.device)
+        out = torch.empty(B, cfg["en_bottleneck_width"], cfg["en_pool_kernel_size"], dtype=torch.float32, device=wave.device)
+        p, keep = WavenetFn._ptrs(params, n)
+        L.check(L.lib().avvad_wavenet_fwd(L.ptr(wave), C.byref(p), L.ptr(out), C.byref(d), L.ptr(ws), ws.numel() * 4,
+                                          _stream()), "avvad_wavenet_fwd")
+        ctx.cfg = cfg
+        ctx.save_for_backward(wave, ws, *[t for t in params if t is not None])
+        ctx.mask = [t is not None for t in params]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        cfg = ctx.cfg
+        saved = ctx.saved_tensors
+        wave, ws = saved[0], saved[1]
+        it = iter(saved[2:])
+        params = tuple(next(it) if m else None for m in ctx.mask)
+        n = len(cfg["dilations"])
+        B, qc, Lin = wave.shape
+        dil_arr = (C.c_int * max(1, n))(*cfg["dilations"])
+        d = WavenetFn._desc(cfg, B, Lin, dil_arr, True)
+        grads = tuple(None if t is None else torch.zeros_like(t) for t in params)
+        dwave = torch.empty_like(wave) if ctx.needs_input_grad[0] else None
+        p, keep1 = WavenetFn._ptrs(params, n)
+        g, keep2 = WavenetFn._ptrs(grads, n)
+        L.check(L.lib().avvad_wavenet_bwd(L.ptr(wave), C.byref(p), L.ptr(_dev(dout, "dout")), C.byref(g), L.ptr(dwave),
+                                          C.byref(d), L.ptr(ws), ws.numel() * 4, _stream()), "avvad_wavenet_bwd")
+        return (dwave, None) + grads
+
+
+# --------------------------------------------------------------------------- ResNet-18 trunk
+class TrunkFn(torch.autograd.Function):
+    """frames (N,H,W) -> (N,512).  tensors: 20 conv_w, 20 bn_w, 20 bn_b, 20 running_mean, 20 running_var
+    in the conv index order of include/avvad.h.  Running stats are updated in place when training."""
+
+    @staticmethod
+    def _params(ts):
+        n = L.TRUNK_NCONV
+        p = L.TrunkParams()
+        for i in range(n):
+            p.conv_w[i] = ts[i].data_ptr()
+            p.bn_w[i] = ts[n + i].data_ptr()
+            p.bn_b[i] = ts[2 * n + i].data_ptr()
+            p.bn_rm[i] = ts[3 * n + i].data_ptr()
+            p.bn_rv[i] = ts[4 * n + i].data_ptr()
+        return p
+
+    @staticmethod
+    def forward(ctx, frames, training, momentum, eps, *ts):
+        frames = _dev(frames, "frames")
+        N, H, W = frames.shape
+        n = L.TRUNK_NCONV
+        if len(ts) != 5 * n:
+            raise L.AvvadError("trunk: expected %d tensors" % (5 * n))
+        ts = tuple(_dev(t, "trunk tensor") for t in ts)
+        save = any(ctx.needs_input_grad[4:4 + 3 * n])
+        d = L.TrunkDesc(N, H, W, int(training), float(momentum), float(eps), int(save))
+        ws = _ws(L.lib().avvad_trunk_workspace(C.byref(d)), frames.device)
+        feat = torch.empty(N, 512, dtype=torch.float32, device=frames.device)
+        p = TrunkFn._params(ts)
+        L.check(L.lib().avvad_trunk_fwd(L.ptr(frames), C.byref(p), L.ptr(feat), C.byref(d), L.ptr(ws), ws.numel() * 4,
+                                        _stream()), "avvad_trunk_fwd")
+        if save:
+            ctx.save_for_backward(frames, ws, *ts)
+            ctx.cfg = (int(training), float(momentum), float(eps))
+        return feat
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        saved = ctx.saved_tensors
+        frames, ws, ts = saved[0], saved[1], saved[2:]
+        N, H, W = frames.shape
+        n = L.TRUNK_NCONV
+        training, momentum, eps = ctx.cfg
+        d = L.TrunkDesc(N, H, W, training, momentum, eps, 1)
+        p = TrunkFn._params(ts)
+        g = L.TrunkGrads()
+        grads = []
+        for i in range(3 * n):
+            if ctx.needs_input_grad[4 + i]:
+                gt = torch.zeros_like(ts[i])
+                grads.append(gt)
+                (g.conv_w, g.bn_w, g.bn_b)[i // n][i % n] = gt.data_ptr()
+            else:
+                grads.append(None)
+        L.check(L.lib().avvad_trunk_bwd(L.ptr(frames), C.byref(p), L.ptr(_dev(dfeat, "dfeat")), C.byref(g), C.byref(d),
+                                        L.ptr(ws), ws.numel() * 4, _stream()), "avvad_trunk_bwd")
+        return (None, None, None, None) + tuple(grads) + (None,) * (2 * n)
+
+
+# --------------------------------------------------------------------------- loss
+class MaskedBceFn(torch.autograd.Function):
+    """sum_b mean_{t<len_b} BCE-with-eps(logits, targets)  (models/utils.py:108-113 + train_AV_net.py:298-301)."""
+
+    @staticmethod
+    def forward(ctx, logits, targets, lens32, eps):
+        logits = _dev(logits, "logits")
+        targets = _dev(targets.to(torch.float32), "targets")
+        B, T, Y = logits.shape
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        L.check(L.lib().avvad_bce_masked(L.ptr(logits), L.ptr(targets), L.ptr(lens32), L.ptr(loss), L.ptr(dl), B, T, Y,
+                                         float(eps), _stream()), "avvad_bce_masked")
+        ctx.save_for_backward(dl)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dl,) = ctx.saved_tensors
+        g = dl.clone()
+        L.check(L.lib().avvad_scale_by_device_scalar(L.ptr(g), L.ptr(_dev(dloss, "dloss").view(1)), g.numel(), _stream()),
+                "avvad_scale_by_device_scalar")
+        return g, None, None, None
+
+
+def masked_bce(logits, targets, lengths, eps=1e-8):
+    return MaskedBceFn.apply(logits, targets, lengths_i32(lengths, logits.device), eps)
+
+
+# --------------------------------------------------------------------------- layout helpers
+class ConcatColsFn(torch.autograd.Function):
+    """torch.cat([a, b], dim=2) (AV_Net.py:124), each branch written straight into the buffer."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _dev(a, "a"), _dev(b, "b")
+        rows = a.numel() // a.shape[-1]
+        ca, cb = a.shape[-1], b.shape[-1]
+        y = torch.empty(a.shape[:-1] + (ca + cb,), dtype=torch.float32, device=a.device)
+        lib = L.lib()
+        L.check(lib.avvad_copy_cols(L.ptr(a), L.ptr(y), rows, ca, ca, 0, ca + cb, 0, _stream()), "avvad_copy_cols")
+        L.check(lib.avvad_copy_cols(L.ptr(b), L.ptr(y), rows, cb, cb, 0, ca + cb, ca, _stream()), "avvad_copy_cols")
+        ctx.dims = (rows, ca, cb, a.shape, b.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rows, ca, cb, sa, sb = ctx.dims
+        dy = _dev(dy, "dy")
+        lib = L.lib()
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = torch.empty(sa, dtype=torch.float32, device=dy.device)
+            L.check(lib.avvad_copy_cols(L.ptr(dy), L.ptr(da), rows, ca, ca + cb, 0, ca, 0, _stream()), "avvad_copy_cols")
+        if ctx.needs_input_grad[1]:
+            db = torch.empty(sb, dtype=torch.float32, device=dy.device)
+            L.check(lib.avvad_copy_cols(L.ptr(dy), L.ptr(db), rows, cb, ca + cb, ca, cb, 0, _stream()), "avvad_copy_cols")
+        return da, db
+
+
+class TransposeLast2Fn(torch.autograd.Function):
+    """(B,C,T) -> (B,T,C): encoder output to the LSTM's batch-first layout."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _dev(x, "x")
+        B, Cc, T = x.shape
+        y = torch.empty(B, T, Cc, dtype=torch.float32, device=x.device)
+        L.check(L.lib().avvad_transpose_last2(L.ptr(x), L.ptr(y), B, Cc, T, _stream()), "avvad_transpose_last2")
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _dev(dy, "dy")
+        B, T, Cc = dy.shape
+        dx = torch.empty(B, Cc, T, dtype=torch.float32, device=dy.device)
+        L.check(L.lib().avvad_transpose_last2(L.ptr(dy), L.ptr(dx), B, T, Cc, _stream()), "avvad_transpose_last2")
+        return dx

@@ -1,0 +1,40 @@
+// common.h -- shared device helpers for libavvad_hip.so (gfx950 / CDNA4 only)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "avvad.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define AVVAD_LAUNCH_CHECK()                         \
+  do {                                               \
+    if (hipGetLastError() != hipSuccess) return AVVAD_ELAUNCH; \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// fp32-input MFMA 32x32x2: D(32x32) += A(32x2) . B(2x32).
+//   lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31];
+//   D element reg r of lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+// row of D register r for lane-half h
+__device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// Bijective XCD-aware remap of a linear block id: blocks that the dispatcher
+// round-robins onto one XCD (ids congruent mod 8) get a contiguous chunk of
+// logical tiles, so neighbouring tiles share that XCD's L2.  Speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int q = nblk >> 3, r = nblk & 7, x = bid & 7, j = bid >> 3;
+  return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}

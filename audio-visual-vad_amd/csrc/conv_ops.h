@@ -1,0 +1,176 @@
+// conv_ops.h -- NHWC convolution operand functors for the igemm engine.
+//
+// Geometry of one Conv2d (square kernel / stride / pad, no bias, groups=1):
+//   x  [N][H][W][C]   ->   y [N][Ho][Wo][Co]
+// forward : M = N*Ho*Wo pixels, N = Co, K = KH*KW*C   A = im2col(x)      B = Wf[(kh,kw,c)][co]
+// dgrad   : M = N*H*W pixels,   N = C,  K = KH*KW*Co  A = im2col'(dy)    B = Wd[(kh,kw,co)][c]
+// wgrad   : M = KH*KW*C,        N = Co, K = N*Ho*Wo   A = x gathered^T   B = dy[(pixel)][co]
+// C and Co are multiples of 32 for every trunk conv but the stem (C = 1),
+// which has its own scalar-gather functors.
+#pragma once
+#include "igemm.h"
+
+namespace convop {
+
+struct Geom {
+  int N, H, W, C, Ho, Wo, Co, KS, stride, pad;
+};
+
+// ---- forward A: rows = output pixels, K = (kh,kw,c), c contiguous (16-byte loads)
+struct Im2colFwd {
+  static constexpr bool KCONTIG = true;
+  static constexpr int VEC = 4;
+  struct Ctx { int base, hi0, wi0; };
+  const float* x;
+  Geom g;
+  int M;
+  __device__ __forceinline__ Ctx prep(int m) const {
+    Ctx c;
+    if (m >= M) { c.base = -1; c.hi0 = c.wi0 = 0; return c; }
+    const int hw = g.Ho * g.Wo;
+    const int n = m / hw, r = m - n * hw;
+    const int ho = r / g.Wo, wo = r - ho * g.Wo;
+    c.base = n * g.H * g.W;
+    c.hi0 = ho * g.stride - g.pad;
+    c.wi0 = wo * g.stride - g.pad;
+    return c;
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
+    const int seg = k0 / g.C;  // wave-uniform: C % 32 == 0
+    const int c0 = k0 - seg * g.C + kin;
+    const int kh = seg / g.KS, kw = seg - kh * g.KS;
+    const int hi = c.hi0 + kh, wi = c.wi0 + kw;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (c.base >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
+      const float4 t = *reinterpret_cast<const float4*>(x + ((long)(c.base + hi * g.W + wi) * g.C + c0));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  }
+};
+
+// ---- dgrad A: rows = INPUT pixels, K = (kh,kw,co), gathers dy
+struct Im2colDgrad {
+  static constexpr bool KCONTIG = true;
+  static constexpr int VEC = 4;
+  struct Ctx { int base, hp, wp; };
+  const float* dy;
+  Geom g;
+  int M;
+  __device__ __forceinline__ Ctx prep(int m) const {
+    Ctx c;
+    if (m >= M) { c.base = -1; c.hp = c.wp = 0; return c; }
+    const int hw = g.H * g.W;
+    const int n = m / hw, r = m - n * hw;
+    const int hi = r / g.W, wi = r - hi * g.W;
+    c.base = n * g.Ho * g.Wo;
+    c.hp = hi + g.pad;
+    c.wp = wi + g.pad;
+    return c;
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
+    const int seg = k0 / g.Co;
+    const int c0 = k0 - seg * g.Co + kin;
+    const int kh = seg / g.KS, kw = seg - kh * g.KS;
+    const int th = c.hp - kh, tw = c.wp - kw;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (c.base < 0 || th < 0 || tw < 0) return;
+    int ho = th, wo = tw;
+    if (g.stride == 2) {
+      if ((th | tw) & 1) return;
+      ho >>= 1; wo >>= 1;
+    }
+    if (ho < g.Ho && wo < g.Wo) {
+      const float4 t = *reinterpret_cast<const float4*>(dy + ((long)(c.base + ho * g.Wo + wo) * g.Co + c0));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  }
+};
+
+// ---- wgrad A: A[m = (kh,kw,c)][k = output pixel] = x[n, ho*s-p+kh, wo*s-p+kw, c]; contiguous along m
+struct WgradX {
+  static constexpr bool KCONTIG = false;
+  static constexpr int VEC = 4;
+  struct Ctx { int kh, kw, c; };
+  const float* x;
+  Geom g;
+  int M, K;
+  __device__ __forceinline__ Ctx prep(int m) const {
+    Ctx c;
+    if (m >= M) { c.kh = -1; c.kw = c.c = 0; return c; }
+    const int seg = m / g.C;
+    c.c = m - seg * g.C;
+    c.kh = seg / g.KS;
+    c.kw = seg - c.kh * g.KS;
+    return c;
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
+    const int k = k0 + kin;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (c.kh < 0 || k >= K) return;
+    const int hw = g.Ho * g.Wo;
+    const int n = k / hw, r = k - n * hw;
+    const int ho = r / g.Wo, wo = r - ho * g.Wo;
+    const int hi = ho * g.stride - g.pad + c.kh, wi = wo * g.stride - g.pad + c.kw;
+    if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
+      const float4 t = *reinterpret_cast<const float4*>(x + ((long)((n * g.H + hi) * g.W + wi) * g.C + c.c));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  }
+};
+
+// ---- stem (C = 1): scalar gathers
+struct StemFwd {  // rows = output pixels, K = KS*KS (49), element = x[n, ho*2-3+kh, wo*2-3+kw]
+  static constexpr bool KCONTIG = true;
+  static constexpr int VEC = 1;
+  struct Ctx { int base, hi0, wi0; };
+  const float* x;
+  Geom g;
+  int M, K;
+  __device__ __forceinline__ Ctx prep(int m) const {
+    Ctx c;
+    if (m >= M) { c.base = -1; c.hi0 = c.wi0 = 0; return c; }
+    const int hw = g.Ho * g.Wo;
+    const int n = m / hw, r = m - n * hw;
+    const int ho = r / g.Wo, wo = r - ho * g.Wo;
+    c.base = n * g.H * g.W;
+    c.hi0 = ho * g.stride - g.pad;
+    c.wi0 = wo * g.stride - g.pad;
+    return c;
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
+    const int k = k0 + kin;
+    const int kh = k / g.KS, kw = k - kh * g.KS;
+    const int hi = c.hi0 + kh, wi = c.wi0 + kw;
+    v[0] = 0.f;
+    if (c.base >= 0 && k < K && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W)
+      v[0] = x[c.base + hi * g.W + wi];
+  }
+};
+
+struct StemWgradX {  // A[m = (kh,kw)][k = output pixel]
+  static constexpr bool KCONTIG = false;
+  static constexpr int VEC = 1;
+  struct Ctx { int kh, kw; };
+  const float* x;
+  Geom g;
+  int M, K;
+  __device__ __forceinline__ Ctx prep(int m) const {
+    Ctx c;
+    if (m >= M) { c.kh = -1; c.kw = 0; return c; }
+    c.kh = m / g.KS;
+    c.kw = m - c.kh * g.KS;
+    return c;
+  }
+  __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
+    const int k = k0 + kin;
+    v[0] = 0.f;
+    if (c.kh < 0 || k >= K) return;
+    const int hw = g.Ho * g.Wo;
+    const int n = k / hw, r = k - n * hw;
+    const int ho = r / g.Wo, wo = r - ho * g.Wo;
+    const int hi = ho * g.stride - g.pad + c.kh, wi = wo * g.stride - g.pad + c.kw;
+    if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) v[0] = x[(n * g.H + hi) * g.W + wi];
+  }
+};
+
+}  // namespace convop

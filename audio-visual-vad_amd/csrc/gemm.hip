@@ -1,0 +1,58 @@
+// gemm.hip -- dense fp32 GEMM entry point on the igemm engine (NN / NT / TN / TT).
+// Replaces the nn.LSTM projections and nn.Linear of the reference heads
+// (packages/models/Audio_Net.py:30-35,51-59; Video_Net.py:45-51,102-116; AV_Net.py:53-58,128-140)
+// and their autograd backward.
+#include "gemm_api.h"
+
+namespace {
+
+template <int BM, int BN, class AOp, class BOp>
+int run2(const AOp& a, const BOp& b, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s) {
+  return igemm::launch<BM, BN>(a, b, e, d->M, d->N, d->K, d->split_k, s);
+}
+
+template <class AOp, class BOp>
+int run1(const AOp& a, const BOp& b, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s) {
+  if (d->M <= 64 || d->N <= 64) return run2<64, 64>(a, b, e, d, s);
+  return run2<128, 128>(a, b, e, d, s);
+}
+
+template <class AOp>
+int runA(const AOp& a, const float* B, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s) {
+  if (d->transB) {  // stored [N][K]
+    igemm::RowPlain b{B, d->ldb, d->N, d->K, d->relu_b};
+    return run1(a, b, e, d, s);
+  }
+  const bool v4 = (d->ldb % 4 == 0) && (d->N % 4 == 0) && ((uintptr_t)B % 16 == 0);
+  if (v4) {
+    igemm::ColPlain<4> b{B, d->ldb, d->N, d->K, d->relu_b};
+    return run1(a, b, e, d, s);
+  }
+  igemm::ColPlain<1> b{B, d->ldb, d->N, d->K, d->relu_b};
+  return run1(a, b, e, d, s);
+}
+
+}  // namespace
+
+int avvad_gemm_impl(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d, hipStream_t s) {
+  if (!A || !B || !C || !d || d->M <= 0 || d->N <= 0 || d->K <= 0) return AVVAD_EINVAL;
+  if (d->split_k > 1 && !d->accumulate) return AVVAD_EINVAL;  // partials are atomically added onto C
+  igemm::EpiStore e{C, d->ldc, bias, d->split_k > 1 ? 2 : (d->accumulate ? 1 : 0)};
+  if (bias && d->split_k > 1) return AVVAD_EINVAL;
+  if (!d->transA) {  // [M][K]
+    igemm::RowPlain a{A, d->lda, d->M, d->K, d->relu_a};
+    return runA(a, B, e, d, s);
+  }
+  const bool v4 = (d->lda % 4 == 0) && (d->M % 4 == 0) && ((uintptr_t)A % 16 == 0);
+  if (v4) {
+    igemm::ColPlain<4> a{A, d->lda, d->M, d->K, d->relu_a};
+    return runA(a, B, e, d, s);
+  }
+  igemm::ColPlain<1> a{A, d->lda, d->M, d->K, d->relu_a};
+  return runA(a, B, e, d, s);
+}
+
+extern "C" int avvad_gemm_f32(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d,
+                              avvad_stream_t s) {
+  return avvad_gemm_impl(A, B, bias, C, d, (hipStream_t)s);
+}

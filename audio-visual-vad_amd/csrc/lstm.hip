@@ -1,0 +1,202 @@
+// lstm.hip -- packed-sequence LSTM layer, forward and backward (BPTT).
+//
+// Replaces pack_padded_sequence -> nn.LSTM -> pad_packed_sequence(total_length=T):
+//   packages/models/Audio_Net.py:50-56, Video_Net.py:102-113, AV_Net.py:127-137.
+// Packed semantics as masking: a sequence's state stops at its length, padded
+// output steps are zero (so h_{t-1} can simply be read back from y[:, t-1]).
+//
+// Structure per layer: one big input-projection GEMM over all (b,t) rows, then
+// per step a small recurrent GEMM (split-K, float-atomic accumulate onto the
+// pre-activations) + one fused gate kernel.  The activated gates overwrite the
+// pre-activations in the workspace and are what backward consumes.
+#include "gemm_api.h"
+
+namespace {
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+__global__ void add_bias2(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) o[i] = a[i] + b[i];
+}
+
+// gates G[b][t][4H] (pre-activation in, activated out), cell Cs[b][t][H], y[b][t][H]
+__global__ void lstm_gates_fwd(float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ y,
+                               const int* __restrict__ lengths, int B, int T, int H, int t) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, j = idx - b * H;
+  float* g = G + ((long)b * T + t) * 4 * H;
+  const long o = ((long)b * T + t) * H + j;
+  if (t >= lengths[b]) {
+    g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f; g[3 * H + j] = 0.f;
+    Cs[o] = 0.f; y[o] = 0.f;
+    return;
+  }
+  const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[H + j]), gg = tanhf(g[2 * H + j]), og = sigmoidf_(g[3 * H + j]);
+  const float cp = t > 0 ? Cs[o - H] : 0.f;
+  const float c = fg * cp + ig * gg;
+  g[j] = ig; g[H + j] = fg; g[2 * H + j] = gg; g[3 * H + j] = og;
+  Cs[o] = c;
+  y[o] = og * tanhf(c);
+}
+
+// in: activated gates in G, dy[b][t], DH (recurrent dh from step t+1, consumed and zeroed), DC (dc from t+1)
+// out: d(pre-activation gates) in G (in place), DC for step t-1
+__global__ void lstm_gates_bwd(float* __restrict__ G, const float* __restrict__ Cs, const float* __restrict__ dy,
+                               float* __restrict__ DH, float* __restrict__ DC, const int* __restrict__ lengths, int B,
+                               int T, int H, int t) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * H) return;
+  const int b = idx / H, j = idx - b * H;
+  float* g = G + ((long)b * T + t) * 4 * H;
+  const long o = ((long)b * T + t) * H + j;
+  const float dhr = DH[idx];
+  DH[idx] = 0.f;
+  if (t >= lengths[b]) {
+    g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f; g[3 * H + j] = 0.f;
+    DC[idx] = 0.f;
+    return;
+  }
+  const float ig = g[j], fg = g[H + j], gg = g[2 * H + j], og = g[3 * H + j];
+  const float c = Cs[o], cp = t > 0 ? Cs[o - H] : 0.f;
+  const float tc = tanhf(c);
+  const float dh = dy[o] + dhr;
+  const float dc = DC[idx] + dh * og * (1.f - tc * tc);
+  g[j] = dc * gg * ig * (1.f - ig);
+  g[H + j] = dc * cp * fg * (1.f - fg);
+  g[2 * H + j] = dc * ig * (1.f - gg * gg);
+  g[3 * H + j] = dh * tc * og * (1.f - og);
+  DC[idx] = dc * fg;
+}
+
+__global__ void shift_time(const float* __restrict__ y, float* __restrict__ ys, int B, int T, int H) {
+  const long n = (long)B * T * H;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)((i / H) % T);
+    ys[i] = t > 0 ? y[i - H] : 0.f;
+  }
+}
+
+__global__ void fill0(float* p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+// out[c] += sum_r X[r][c]  (and out2 if given)
+__global__ void __launch_bounds__(256)
+    colsum_acc(const float* __restrict__ X, int rows, int cols, float* __restrict__ out, float* __restrict__ out2) {
+  __shared__ float sm[256];
+  const int t = threadIdx.x, c = blockIdx.x * 64 + (t & 63), rl = t >> 6;
+  float s = 0.f;
+  if (c < cols)
+    for (int r = rl; r < rows; r += 4) s += X[(long)r * cols + c];
+  sm[t] = s;
+  __syncthreads();
+  if (rl == 0 && c < cols) {
+    const float v = sm[t] + sm[t + 64] + sm[t + 128] + sm[t + 192];
+    out[c] += v;
+    if (out2) out2[c] += v;
+  }
+}
+
+struct Ws {
+  float *G, *Cs, *bias, *DH, *DC, *Ys;
+  size_t total;
+};
+static Ws carve(const avvad_lstm_desc* d, float* base) {
+  Ws w;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return base ? base + o : (float*)nullptr; };
+  const size_t B = d->B, T = d->T, H = d->H;
+  w.G = take(B * T * 4 * H);
+  w.Cs = take(B * T * H);
+  w.bias = take(4 * H);
+  w.DH = take(B * H);
+  w.DC = take(B * H);
+  w.Ys = take(B * T * H);
+  w.total = off;
+  return w;
+}
+static inline int grid1(long n) { long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+static inline int pick_split(int M, int N, int K) {
+  const int tiles = cdiv(M, (M <= 64 || N <= 64) ? 64 : 128) * cdiv(N, (M <= 64 || N <= 64) ? 64 : 128);
+  int s = 512 / (tiles > 0 ? tiles : 1);
+  const int kt = cdiv(K, igemm::BK);
+  if (s > kt) s = kt;
+  if (s > 16) s = 16;
+  return s < 1 ? 1 : s;
+}
+
+}  // namespace
+
+extern "C" size_t avvad_lstm_workspace(const avvad_lstm_desc* d) {
+  if (!d || d->B <= 0 || d->T <= 0 || d->H <= 0) return 0;
+  return carve(d, nullptr).total * sizeof(float);
+}
+
+extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
+                                    const float* b_hh, float* y, const avvad_lstm_desc* d, void* wsv, size_t ws_bytes,
+                                    avvad_stream_t sv) {
+  if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !y || !d || !wsv || !d->lengths || d->B <= 0 || d->T <= 0 || d->In <= 0 ||
+      d->H <= 0)
+    return AVVAD_EINVAL;
+  hipStream_t s = (hipStream_t)sv;
+  Ws w = carve(d, (float*)wsv);
+  if (ws_bytes < w.total * sizeof(float)) return AVVAD_EWORKSPACE;
+  const int B = d->B, T = d->T, H = d->H, In = d->In;
+  hipLaunchKernelGGL(add_bias2, dim3(cdiv(4 * H, 256)), dim3(256), 0, s, b_ih, b_hh, w.bias, 4 * H);
+  int rc;
+  avvad_gemm_desc gd = gemm_desc(B * T, 4 * H, In, In, In, 4 * H, 0, 1, 0, 1);
+  if ((rc = avvad_gemm_impl(x, w_ih, w.bias, w.G, &gd, s))) return rc;
+  const int split = pick_split(B, 4 * H, H);
+  for (int t = 0; t < T; ++t) {
+    if (t > 0) {
+      avvad_gemm_desc rd = gemm_desc(B, 4 * H, H, T * H, H, T * 4 * H, 0, 1, 1, split);
+      if ((rc = avvad_gemm_impl(y + (long)(t - 1) * H, w_hh, nullptr, w.G + (long)t * 4 * H, &rd, s))) return rc;
+    }
+    hipLaunchKernelGGL(lstm_gates_fwd, dim3(cdiv(B * H, 256)), dim3(256), 0, s, w.G, w.Cs, y, d->lengths, B, T, H, t);
+  }
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const float* w_hh, const float* y, const float* dy,
+                                    float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
+                                    const avvad_lstm_desc* d, void* wsv, size_t ws_bytes, avvad_stream_t sv) {
+  if (!x || !w_ih || !w_hh || !y || !dy || !d || !wsv || !d->lengths) return AVVAD_EINVAL;
+  hipStream_t s = (hipStream_t)sv;
+  Ws w = carve(d, (float*)wsv);
+  if (ws_bytes < w.total * sizeof(float)) return AVVAD_EWORKSPACE;
+  const int B = d->B, T = d->T, H = d->H, In = d->In;
+  int rc;
+  hipLaunchKernelGGL(fill0, dim3(grid1(B * H)), dim3(256), 0, s, w.DH, (long)B * H);
+  hipLaunchKernelGGL(fill0, dim3(grid1(B * H)), dim3(256), 0, s, w.DC, (long)B * H);
+  const int split = pick_split(B, H, 4 * H);
+  for (int t = T - 1; t >= 0; --t) {
+    hipLaunchKernelGGL(lstm_gates_bwd, dim3(cdiv(B * H, 256)), dim3(256), 0, s, w.G, w.Cs, dy, w.DH, w.DC, d->lengths, B, T,
+                       H, t);
+    if (t > 0) {  // DH = dG_t . W_hh   ([B][4H] x [4H][H])
+      avvad_gemm_desc rd = gemm_desc(B, H, 4 * H, T * 4 * H, H, H, 0, 0, 1, split);
+      if ((rc = avvad_gemm_impl(w.G + (long)t * 4 * H, w_hh, nullptr, w.DH, &rd, s))) return rc;
+    }
+  }
+  const int R = B * T;
+  if (dx) {
+    avvad_gemm_desc g1 = gemm_desc(R, In, 4 * H, 4 * H, In, In, 0, 0, 0, 1);
+    if ((rc = avvad_gemm_impl(w.G, w_ih, nullptr, dx, &g1, s))) return rc;
+  }
+  if (dw_ih) {
+    avvad_gemm_desc g2 = gemm_desc(4 * H, In, R, 4 * H, In, In, 1, 0, 1, pick_split(4 * H, In, R));
+    if ((rc = avvad_gemm_impl(w.G, x, nullptr, dw_ih, &g2, s))) return rc;
+  }
+  if (dw_hh) {
+    hipLaunchKernelGGL(shift_time, dim3(grid1((long)R * H)), dim3(256), 0, s, y, w.Ys, B, T, H);
+    avvad_gemm_desc g3 = gemm_desc(4 * H, H, R, 4 * H, H, H, 1, 0, 1, pick_split(4 * H, H, R));
+    if ((rc = avvad_gemm_impl(w.G, w.Ys, nullptr, dw_hh, &g3, s))) return rc;
+  }
+  if (db_ih || db_hh)
+    hipLaunchKernelGGL(colsum_acc, dim3(cdiv(4 * H, 64)), dim3(256), 0, s, w.G, R, 4 * H, db_ih ? db_ih : db_hh,
+                       (db_ih && db_hh) ? db_hh : (float*)nullptr);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}

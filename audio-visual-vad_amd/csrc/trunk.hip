@@ -1,0 +1,621 @@
+// trunk.hip -- ResNet-18 trunk over gray lip crops: forward and backward.
+//
+// Replaces `self.features(video).squeeze()` (+ the 3x channel repeat in front of it)
+// of the reference: packages/models/Video_Net.py:60-81, packages/models/AV_Net.py:78-94,
+// i.e. torchvision.models.resnet18 children [:-1].
+//
+// Data layout in HBM: activations NHWC fp32 (channel-contiguous: an im2col row
+// is a run of 128-byte lines), weights re-packed once per call from the
+// state_dict's OIHW into [(kh,kw,c)][co] (forward B operand) and
+// [(kh,kw,co)][c] (dgrad B operand).  The reference's 3 identical input
+// channels are folded into the stem's weights (sum over c), so the frame is
+// read once as a 1-channel image.
+//
+// Kernels: every convolution (forward, dgrad, wgrad) is the fp32-MFMA
+// implicit GEMM of igemm.h; BatchNorm statistics are a two-stage column
+// reduction in fp64; normalisation / ReLU / residual add / pooling are fused
+// elementwise kernels with 16-byte accesses.
+#include "conv_ops.h"
+
+using convop::Geom;
+
+namespace {
+
+constexpr int NCONV = AVVAD_TRUNK_NCONV;
+constexpr int MAXC = 512;
+constexpr int STAT_CHUNKS = 512;
+
+// ------------------------------------------------------------------ static network description
+struct ConvSpec {
+  int cin, cout, ks, stride, pad;
+  int stage;    // -1 stem
+  int role;     // 0 stem, 1 block conv1, 2 block conv2, 3 downsample
+};
+
+struct Plan {
+  int N, H, W;
+  int h[6], w[6];  // 0: input, 1: stem out, 2: pooled / stage0, 3..5: stage1..3
+  ConvSpec conv[NCONV];
+  Geom geom[NCONV];
+  // workspace offsets in floats
+  size_t wf[NCONV], wd[NCONV];
+  size_t bn_scale, bn_shift, bn_mean, bn_invstd;  // [NCONV][MAXC]
+  size_t coef;                                    // [3][MAXC] backward coefficients
+  size_t part;                                    // doubles: [STAT_CHUNKS][2][MAXC]
+  size_t c0, p0;
+  size_t blk[8][5];  // c1, a1, c2, cd, out
+  size_t G[4], g0, wg;
+  size_t total;
+};
+
+static void make_plan(const avvad_trunk_desc* d, Plan* p) {
+  p->N = d->N; p->H = d->H; p->W = d->W;
+  p->h[0] = d->H; p->w[0] = d->W;
+  p->h[1] = (d->H + 6 - 7) / 2 + 1; p->w[1] = (d->W + 6 - 7) / 2 + 1;
+  p->h[2] = (p->h[1] + 2 - 3) / 2 + 1; p->w[2] = (p->w[1] + 2 - 3) / 2 + 1;
+  for (int s = 3; s < 6; ++s) { p->h[s] = (p->h[s - 1] + 2 - 3) / 2 + 1; p->w[s] = (p->w[s - 1] + 2 - 3) / 2 + 1; }
+  int i = 0;
+  p->conv[i++] = {1, 64, 7, 2, 3, -1, 0};
+  int cin = 64;
+  const int widths[4] = {64, 128, 256, 512};
+  for (int s = 0; s < 4; ++s)
+    for (int b = 0; b < 2; ++b) {
+      const int c = widths[s], st = (b == 0 && s > 0) ? 2 : 1;
+      p->conv[i++] = {cin, c, 3, st, 1, s, 1};
+      p->conv[i++] = {c, c, 3, 1, 1, s, 2};
+      if (b == 0 && s > 0) p->conv[i++] = {cin, c, 1, 2, 0, s, 3};
+      cin = c;
+    }
+  // geometry
+  i = 0;
+  p->geom[i++] = {d->N, p->h[0], p->w[0], 1, p->h[1], p->w[1], 64, 7, 2, 3};
+  for (int s = 0; s < 4; ++s)
+    for (int b = 0; b < 2; ++b) {
+      const int hin = (b == 0 && s > 0) ? p->h[s + 1] : p->h[s + 2], win = (b == 0 && s > 0) ? p->w[s + 1] : p->w[s + 2];
+      const int ho = p->h[s + 2], wo = p->w[s + 2];
+      const ConvSpec c1 = p->conv[i];
+      p->geom[i++] = {d->N, hin, win, c1.cin, ho, wo, c1.cout, 3, c1.stride, 1};
+      const ConvSpec c2 = p->conv[i];
+      p->geom[i++] = {d->N, ho, wo, c2.cin, ho, wo, c2.cout, 3, 1, 1};
+      if (b == 0 && s > 0) { const ConvSpec cd = p->conv[i]; p->geom[i++] = {d->N, hin, win, cd.cin, ho, wo, cd.cout, 1, 2, 0}; }
+    }
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
+  for (i = 0; i < NCONV; ++i) {
+    const ConvSpec& c = p->conv[i];
+    const size_t n = (size_t)c.ks * c.ks * c.cin * c.cout;
+    p->wf[i] = take(n);
+    p->wd[i] = (i == 0) ? 0 : take(n);
+  }
+  p->bn_scale = take(NCONV * MAXC); p->bn_shift = take(NCONV * MAXC);
+  p->bn_mean = take(NCONV * MAXC); p->bn_invstd = take(NCONV * MAXC);
+  p->coef = take(3 * MAXC);
+  p->part = take((size_t)STAT_CHUNKS * 2 * MAXC * 2);  // doubles
+  const size_t N = d->N;
+  p->c0 = take(N * p->h[1] * p->w[1] * 64);
+  p->p0 = take(N * p->h[2] * p->w[2] * 64);
+  for (int s = 0; s < 4; ++s)
+    for (int b = 0; b < 2; ++b) {
+      const size_t n = N * p->h[s + 2] * p->w[s + 2] * widths[s];
+      for (int j = 0; j < 5; ++j) p->blk[s * 2 + b][j] = (j == 3 && !(b == 0 && s > 0)) ? 0 : take(n);
+    }
+  if (d->save_for_backward) {
+    const size_t gmax = N * p->h[2] * p->w[2] * 64;  // stage0 is the largest block tensor
+    for (int j = 0; j < 4; ++j) p->G[j] = take(gmax);
+    p->g0 = take(N * p->h[1] * p->w[1] * 64);
+    p->wg = take((size_t)9 * 512 * 512);
+  }
+  p->total = off;
+}
+
+// ------------------------------------------------------------------ weight (un)packing
+__global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd, int Co, int C, int KS) {
+  const int n = Co * C * KS * KS;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    // i indexes OIHW
+    int r = i;
+    const int kw = r % KS; r /= KS;
+    const int kh = r % KS; r /= KS;
+    const int c = r % C; const int co = r / C;
+    const float v = w[i];
+    wf[((long)(kh * KS + kw) * C + c) * Co + co] = v;
+    if (wd) wd[((long)(kh * KS + kw) * Co + co) * C + c] = v;
+  }
+}
+// stem: fold the 3 identical input channels (Video_Net.py:64): Wf[kh*7+kw][co] = sum_c w[co][c][kh][kw]
+__global__ void pack_stem(const float* __restrict__ w, float* __restrict__ wf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 49) return;
+  const int co = i / 49, k = i % 49;
+  wf[k * 64 + co] = w[(co * 3 + 0) * 49 + k] + w[(co * 3 + 1) * 49 + k] + w[(co * 3 + 2) * 49 + k];
+}
+__global__ void unpack_wgrad(const float* __restrict__ pk, float* __restrict__ dw, int Co, int C, int KS) {
+  const int n = Co * C * KS * KS;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int r = i;
+    const int kw = r % KS; r /= KS;
+    const int kh = r % KS; r /= KS;
+    const int c = r % C; const int co = r / C;
+    dw[i] += pk[((long)(kh * KS + kw) * C + c) * Co + co];
+  }
+}
+__global__ void unpack_stem_wgrad(const float* __restrict__ pk, float* __restrict__ dw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= 64 * 3 * 49) return;
+  const int co = i / 147, k = i % 49;
+  dw[i] += pk[k * 64 + co];
+}
+
+// ------------------------------------------------------------------ column reductions ([M][C] fp32 -> per-channel fp64 sums)
+// MODE 0: sum x, sum x^2           (batch statistics)
+// MODE 1: sum g, sum g*xhat  with g = dy * (ymask > 0 if ymask)   (BatchNorm backward)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    col_reduce(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask,
+               const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C, long rows_per_chunk,
+               double* __restrict__ part) {
+  __shared__ double sm[256 * 8];
+  const int t = threadIdx.x;
+  const int Q = C >> 2, RL = 256 / Q;
+  const int q = t % Q, rl = t / Q;
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[q * 4 + j]; is[j] = invstd[q * 4 + j]; }
+  }
+  const long r0 = blockIdx.x * rows_per_chunk;
+  const long r1 = min(M, r0 + rows_per_chunk);
+  if (rl < RL)
+    for (long r = r0 + rl; r < r1; r += RL) {
+      const long o = r * C + q * 4;
+      const float4 v = *reinterpret_cast<const float4*>(x + o);
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += xv[j]; ss[j] += (double)xv[j] * xv[j]; }
+      } else {
+        const float4 d = *reinterpret_cast<const float4*>(dy + o);
+        float g[4] = {d.x, d.y, d.z, d.w};
+        if (ymask) {
+          const float4 y = *reinterpret_cast<const float4*>(ymask + o);
+          if (!(y.x > 0.f)) g[0] = 0.f;
+          if (!(y.y > 0.f)) g[1] = 0.f;
+          if (!(y.z > 0.f)) g[2] = 0.f;
+          if (!(y.w > 0.f)) g[3] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += g[j]; ss[j] += (double)g[j] * ((xv[j] - mu[j]) * is[j]); }
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sm[t * 8 + j] = s[j]; sm[t * 8 + 4 + j] = ss[j]; }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int cq = c >> 2, cj = c & 3;
+    double a = 0, b = 0;
+    for (int l = 0; l < RL; ++l) { a += sm[(l * Q + cq) * 8 + cj]; b += sm[(l * Q + cq) * 8 + 4 + cj]; }
+    part[((long)blockIdx.x * 2 + 0) * C + c] = a;
+    part[((long)blockIdx.x * 2 + 1) * C + c] = b;
+  }
+}
+
+// finalize batch statistics -> scale/shift (+ saved mean/invstd, running-stat update)
+__global__ void bn_finalize(const double* __restrict__ part, int nchunk, long M, int C, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv, int training,
+                            float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                            float* __restrict__ mean_o, float* __restrict__ invstd_o) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, var;
+  if (training) {
+    double s = 0, ss = 0;
+    for (int i = 0; i < nchunk; ++i) { s += part[((long)i * 2 + 0) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
+    const double m = s / (double)M;
+    double v = ss / (double)M - m * m;
+    if (v < 0) v = 0;
+    mean = (float)m; var = (float)v;
+    const double unb = M > 1 ? v * (double)M / (double)(M - 1) : v;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+  } else {
+    mean = rm[c]; var = rv[c];
+  }
+  const float is = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  mean_o[c] = mean;
+  invstd_o[c] = is;
+}
+
+// finalize BatchNorm backward sums -> dgamma/dbeta (accumulated) and the apply coefficients
+//   dx = k0 * (g - k1 - xhat * k2)
+__global__ void bn_bwd_finalize(const double* __restrict__ part, int nchunk, long M, int C, const float* __restrict__ gamma,
+                                const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta, float* __restrict__ coef) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0, ss = 0;
+  for (int i = 0; i < nchunk; ++i) { s += part[((long)i * 2 + 0) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
+  if (dbeta) dbeta[c] += (float)s;
+  if (dgamma) dgamma[c] += (float)ss;
+  coef[c] = gamma[c] * invstd[c];
+  coef[MAXC + c] = training ? (float)(s / (double)M) : 0.f;
+  coef[2 * MAXC + c] = training ? (float)(ss / (double)M) : 0.f;
+}
+
+// ------------------------------------------------------------------ fused elementwise (16-byte accesses, C % 4 == 0)
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return fmaf(x, sc, sh); }
+
+// y = [relu]( x*scale+shift  [+ idn | + idn*iscale+ishift] )
+__global__ void bn_act(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                       const float* __restrict__ idn, const float* __restrict__ iscale, const float* __restrict__ ishift,
+                       float* __restrict__ y, long nquad, int C, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquad; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    float o[4] = {bn_affine(v.x, sc.x, sh.x), bn_affine(v.y, sc.y, sh.y), bn_affine(v.z, sc.z, sh.z), bn_affine(v.w, sc.w, sh.w)};
+    if (idn) {
+      const float4 d = reinterpret_cast<const float4*>(idn)[i];
+      if (iscale) {
+        const float4 a = *reinterpret_cast<const float4*>(iscale + c), b = *reinterpret_cast<const float4*>(ishift + c);
+        o[0] += bn_affine(d.x, a.x, b.x); o[1] += bn_affine(d.y, a.y, b.y);
+        o[2] += bn_affine(d.z, a.z, b.z); o[3] += bn_affine(d.w, a.w, b.w);
+      } else { o[0] += d.x; o[1] += d.y; o[2] += d.z; o[3] += d.w; }
+    }
+    if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dx = k0*(g - k1 - xhat*k2), g = dy*(ymask>0);  optionally also writes g (identity branch of the residual)
+// (dx may alias dy: each element is read, then written, by the same thread)
+__global__ void bn_bwd_apply(const float* __restrict__ x, const float* dy, const float* __restrict__ ymask,
+                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
+                             float* dx, float* gout, long nquad, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquad; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 d = reinterpret_cast<const float4*>(dy)[i];
+    float g[4] = {d.x, d.y, d.z, d.w};
+    if (ymask) {
+      const float4 y = reinterpret_cast<const float4*>(ymask)[i];
+      if (!(y.x > 0.f)) g[0] = 0.f;
+      if (!(y.y > 0.f)) g[1] = 0.f;
+      if (!(y.z > 0.f)) g[2] = 0.f;
+      if (!(y.w > 0.f)) g[3] = 0.f;
+    }
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xs[j] - mean[c + j]) * invstd[c + j];
+      o[j] = coef[c + j] * (g[j] - coef[MAXC + c + j] - xh * coef[2 * MAXC + c + j]);
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (gout) reinterpret_cast<float4*>(gout)[i] = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+
+// stem: p0 = maxpool3x3/2 pad1 ( relu(bn(c0)) )
+__global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
+                                  float* __restrict__ p0, int N, int Hc, int Wc, int Hp, int Wp) {
+  const long total = (long)N * Hp * Wp * 16;  // 64 channels = 16 quads
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 15);
+    long r = i >> 4;
+    const int pw = (int)(r % Wp); r /= Wp;
+    const int ph = (int)(r % Hp); const int n = (int)(r / Hp);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sh = *reinterpret_cast<const float4*>(shift + q * 4);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int dh = 0; dh < 3; ++dh) {
+      const int h = ph * 2 - 1 + dh;
+      if ((unsigned)h >= (unsigned)Hc) continue;
+      for (int dw = 0; dw < 3; ++dw) {
+        const int w = pw * 2 - 1 + dw;
+        if ((unsigned)w >= (unsigned)Wc) continue;
+        const float4 v = *reinterpret_cast<const float4*>(c0 + ((long)(n * Hc + h) * Wc + w) * 64 + q * 4);
+        m[0] = fmaxf(m[0], fmaxf(bn_affine(v.x, sc.x, sh.x), 0.f));
+        m[1] = fmaxf(m[1], fmaxf(bn_affine(v.y, sc.y, sh.y), 0.f));
+        m[2] = fmaxf(m[2], fmaxf(bn_affine(v.z, sc.z, sh.z), 0.f));
+        m[3] = fmaxf(m[3], fmaxf(bn_affine(v.w, sc.w, sh.w), 0.f));
+      }
+    }
+    reinterpret_cast<float4*>(p0)[i] = make_float4(m[0], m[1], m[2], m[3]);
+  }
+}
+
+// stem backward of pool+relu: g0[n,h,w,c] = sum over pooled windows whose max is this element of dp0
+// (the max is recomputed with the identical expression, so equality is exact; zero ties carry no
+// gradient through the ReLU anyway).
+__global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
+                                   const float* __restrict__ p0, const float* __restrict__ dp0, float* __restrict__ g0,
+                                   int N, int Hc, int Wc, int Hp, int Wp) {
+  const long total = (long)N * Hc * Wc * 16;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 15);
+    long r = i >> 4;
+    const int w = (int)(r % Wc); r /= Wc;
+    const int h = (int)(r % Hc); const int n = (int)(r / Hc);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sh = *reinterpret_cast<const float4*>(shift + q * 4);
+    const float4 v = reinterpret_cast<const float4*>(c0)[i];
+    const float y[4] = {fmaxf(bn_affine(v.x, sc.x, sh.x), 0.f), fmaxf(bn_affine(v.y, sc.y, sh.y), 0.f),
+                        fmaxf(bn_affine(v.z, sc.z, sh.z), 0.f), fmaxf(bn_affine(v.w, sc.w, sh.w), 0.f)};
+    float g[4] = {0, 0, 0, 0};
+    const int ph0 = max(0, h / 2), ph1 = min(Hp - 1, (h + 1) / 2);
+    const int pw0 = max(0, w / 2), pw1 = min(Wp - 1, (w + 1) / 2);
+    for (int ph = ph0; ph <= ph1; ++ph)
+      for (int pw = pw0; pw <= pw1; ++pw) {
+        // window of (ph,pw) covers rows 2ph-1..2ph+1
+        if (h < 2 * ph - 1 || h > 2 * ph + 1 || w < 2 * pw - 1 || w > 2 * pw + 1) continue;
+        const long o = ((long)(n * Hp + ph) * Wp + pw) * 64 + q * 4;
+        const float4 pm = *reinterpret_cast<const float4*>(p0 + o), dp = *reinterpret_cast<const float4*>(dp0 + o);
+        if (y[0] > 0.f && pm.x == y[0]) g[0] += dp.x;
+        if (y[1] > 0.f && pm.y == y[1]) g[1] += dp.y;
+        if (y[2] > 0.f && pm.z == y[2]) g[2] += dp.z;
+        if (y[3] > 0.f && pm.w == y[3]) g[3] += dp.w;
+      }
+    reinterpret_cast<float4*>(g0)[i] = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+
+// feat[n][c] = mean over HW of y[n][hw][c]
+__global__ void avgpool_fwd(const float* __restrict__ y, float* __restrict__ feat, int N, int HW, int C) {
+  const long total = (long)N * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long n = i / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += y[(n * HW + p) * C + c];
+    feat[i] = s / (float)HW;
+  }
+}
+__global__ void avgpool_bwd(const float* __restrict__ dfeat, float* __restrict__ dy, int N, int HW, int C) {
+  const long total = (long)N * HW * C;
+  const float inv = 1.f / (float)HW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long n = i / ((long)HW * C);
+    dy[i] = dfeat[n * C + c] * inv;
+  }
+}
+__global__ void zero_f32(float* p, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
+static inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+// ------------------------------------------------------------------ conv launchers
+static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s) {
+  const int M = g.N * g.Ho * g.Wo, K = g.KS * g.KS * g.C;
+  igemm::EpiStore e{y, g.Co, nullptr, 0};
+  igemm::ColPlain<4> b{wf, g.Co, g.Co, K, 0};
+  if (g.C == 1) {
+    convop::StemFwd a{x, g, M, K};
+    return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
+  }
+  if (g.C % 32 || g.Co % 4) return AVVAD_EINVAL;
+  convop::Im2colFwd a{x, g, M};
+  if (g.Co <= 64) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
+  return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s);
+}
+// dx (+)= dgrad
+static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s) {
+  const int M = g.N * g.H * g.W, K = g.KS * g.KS * g.Co;
+  if (g.Co % 32 || g.C % 4) return AVVAD_EINVAL;
+  igemm::EpiStore e{dx, g.C, nullptr, accumulate ? 1 : 0};
+  igemm::ColPlain<4> b{wd, g.C, g.C, K, 0};
+  convop::Im2colDgrad a{dy, g, M};
+  if (g.C <= 64) return igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s);
+  return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s);
+}
+// pk[(kh,kw,c)][co] = wgrad (pk zeroed here; split-K partials are added atomically)
+static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s) {
+  const int M = g.KS * g.KS * g.C, K = g.N * g.Ho * g.Wo;
+  hipLaunchKernelGGL(zero_f32, dim3(ew_grid((long)M * g.Co)), dim3(256), 0, s, pk, (long)M * g.Co);
+  igemm::EpiStore e{pk, g.Co, nullptr, 2};
+  igemm::ColPlain<4> b{dy, g.Co, g.Co, K, 0};
+  const int ktiles = cdiv(K, igemm::BK);
+  if (g.C == 1) {
+    convop::StemWgradX a{x, g, M, K};
+    int split = 1024; if (split > ktiles) split = ktiles;
+    return igemm::launch<64, 64>(a, b, e, M, g.Co, K, split, s);
+  }
+  convop::WgradX a{x, g, M, K};
+  const bool small = g.Co <= 64;
+  const int nb = cdiv(M, 128) * cdiv(g.Co, small ? 64 : 128);
+  int split = cdiv(1024, nb); if (split > ktiles) split = ktiles;
+  if (small) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, split, s);
+  return igemm::launch<128, 128>(a, b, e, M, g.Co, K, split, s);
+}
+
+struct StatCtx { double* part; int nchunk; long rows_per_chunk; };
+static StatCtx stat_ctx(Plan* p, float* ws, long M, int C) {
+  StatCtx c;
+  c.part = reinterpret_cast<double*>(ws + p->part);
+  const int RL = 256 / (C / 4);
+  long per = (M + STAT_CHUNKS - 1) / STAT_CHUNKS;
+  per = (per + RL - 1) / RL * RL;
+  if (per < RL) per = RL;
+  c.rows_per_chunk = per;
+  c.nchunk = cdiv(M, per);
+  return c;
+}
+
+// batch statistics of conv output i -> scale/shift/mean/invstd slots i (+ running stats)
+static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, const avvad_trunk_params* prm,
+                      const avvad_trunk_desc* d, hipStream_t s) {
+  const int C = p->conv[i].cout;
+  StatCtx sc = stat_ctx(p, ws, M, C);
+  if (d->training) {
+    hipLaunchKernelGGL(col_reduce<0>, dim3(sc.nchunk), dim3(256), 0, s, craw, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, M, C, sc.rows_per_chunk, sc.part);
+  }
+  hipLaunchKernelGGL(bn_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], prm->bn_b[i],
+                     prm->bn_rm[i], prm->bn_rv[i], d->training, d->momentum, d->eps, ws + p->bn_scale + i * MAXC,
+                     ws + p->bn_shift + i * MAXC, ws + p->bn_mean + i * MAXC, ws + p->bn_invstd + i * MAXC);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+// BatchNorm backward of conv i:  dx = BN'(x_raw; dy masked by ymask>0); optional gout = masked dy
+static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float* dy, const float* ymask, float* dx,
+                       float* gout, long M, const avvad_trunk_params* prm, const avvad_trunk_grads* g,
+                       const avvad_trunk_desc* d, hipStream_t s) {
+  const int C = p->conv[i].cout;
+  StatCtx sc = stat_ctx(p, ws, M, C);
+  const float* mean = ws + p->bn_mean + i * MAXC;
+  const float* invstd = ws + p->bn_invstd + i * MAXC;
+  hipLaunchKernelGGL(col_reduce<1>, dim3(sc.nchunk), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, M, C,
+                     sc.rows_per_chunk, sc.part);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], invstd,
+                     d->training, g->bn_w[i], g->bn_b[i], ws + p->coef);
+  const long nq = M * C / 4;
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid(nq)), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, ws + p->coef, dx, gout,
+                     nq, C);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+}  // namespace
+
+// ====================================================================== C ABI
+extern "C" size_t avvad_trunk_workspace(const avvad_trunk_desc* d) {
+  if (!d || d->N <= 0 || d->H < 32 || d->W < 32) return 0;
+  Plan p;
+  make_plan(d, &p);
+  return p.total * sizeof(float);
+}
+
+extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* prm, float* feat, const avvad_trunk_desc* d,
+                               void* wsv, size_t ws_bytes, avvad_stream_t sv) {
+  if (!frames || !prm || !feat || !d || !wsv || d->N <= 0 || d->H < 32 || d->W < 32) return AVVAD_EINVAL;
+  hipStream_t s = (hipStream_t)sv;
+  Plan p;
+  make_plan(d, &p);
+  if (ws_bytes < p.total * sizeof(float)) return AVVAD_EWORKSPACE;
+  float* ws = (float*)wsv;
+  int rc;
+  // weights: OIHW -> packed
+  hipLaunchKernelGGL(pack_stem, dim3(cdiv(64 * 49, 256)), dim3(256), 0, s, prm->conv_w[0], ws + p.wf[0]);
+  for (int i = 1; i < NCONV; ++i) {
+    const ConvSpec& c = p.conv[i];
+    const int n = c.cout * c.cin * c.ks * c.ks;
+    hipLaunchKernelGGL(pack_weights, dim3(ew_grid(n)), dim3(256), 0, s, prm->conv_w[i], ws + p.wf[i],
+                       d->save_for_backward ? ws + p.wd[i] : (float*)nullptr, c.cout, c.cin, c.ks);
+  }
+  // stem
+  const long N = d->N;
+  if ((rc = conv_fwd(frames, ws + p.wf[0], ws + p.c0, p.geom[0], s))) return rc;
+  const long M0 = N * p.h[1] * p.w[1];
+  if ((rc = bn_prepare(&p, ws, 0, ws + p.c0, M0, prm, d, s))) return rc;
+  hipLaunchKernelGGL(stem_bn_relu_pool, dim3(ew_grid(N * p.h[2] * p.w[2] * 16)), dim3(256), 0, s, ws + p.c0,
+                     ws + p.bn_scale, ws + p.bn_shift, ws + p.p0, d->N, p.h[1], p.w[1], p.h[2], p.w[2]);
+  // residual stages
+  const float* x = ws + p.p0;
+  int ci = 1;
+  const int widths[4] = {64, 128, 256, 512};
+  for (int st = 0; st < 4; ++st)
+    for (int b = 0; b < 2; ++b) {
+      const int C = widths[st];
+      const size_t* o = p.blk[st * 2 + b];
+      const bool ds = (b == 0 && st > 0);
+      const long M = N * p.h[st + 2] * p.w[st + 2];
+      const long nq = M * C / 4;
+      const int i1 = ci, i2 = ci + 1, id = ci + 2;
+      if ((rc = conv_fwd(x, ws + p.wf[i1], ws + o[0], p.geom[i1], s))) return rc;
+      if ((rc = bn_prepare(&p, ws, i1, ws + o[0], M, prm, d, s))) return rc;
+      hipLaunchKernelGGL(bn_act, dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[0], ws + p.bn_scale + i1 * MAXC,
+                         ws + p.bn_shift + i1 * MAXC, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                         ws + o[1], nq, C, 1);
+      if ((rc = conv_fwd(ws + o[1], ws + p.wf[i2], ws + o[2], p.geom[i2], s))) return rc;
+      if ((rc = bn_prepare(&p, ws, i2, ws + o[2], M, prm, d, s))) return rc;
+      if (ds) {
+        if ((rc = conv_fwd(x, ws + p.wf[id], ws + o[3], p.geom[id], s))) return rc;
+        if ((rc = bn_prepare(&p, ws, id, ws + o[3], M, prm, d, s))) return rc;
+        hipLaunchKernelGGL(bn_act, dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
+                           ws + p.bn_shift + i2 * MAXC, ws + o[3], ws + p.bn_scale + id * MAXC, ws + p.bn_shift + id * MAXC,
+                           ws + o[4], nq, C, 1);
+      } else {
+        hipLaunchKernelGGL(bn_act, dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
+                           ws + p.bn_shift + i2 * MAXC, x, (const float*)nullptr, (const float*)nullptr, ws + o[4], nq, C, 1);
+      }
+      x = ws + o[4];
+      ci += ds ? 3 : 2;
+    }
+  hipLaunchKernelGGL(avgpool_fwd, dim3(ew_grid(N * 512)), dim3(256), 0, s, x, feat, d->N, p.h[5] * p.w[5], 512);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* prm, const float* dfeat,
+                               const avvad_trunk_grads* g, const avvad_trunk_desc* d, void* wsv, size_t ws_bytes,
+                               avvad_stream_t sv) {
+  if (!frames || !prm || !dfeat || !g || !d || !wsv || !d->save_for_backward) return AVVAD_EINVAL;
+  hipStream_t s = (hipStream_t)sv;
+  Plan p;
+  make_plan(d, &p);
+  if (ws_bytes < p.total * sizeof(float)) return AVVAD_EWORKSPACE;
+  float* ws = (float*)wsv;
+  int rc;
+  const long N = d->N;
+  const int widths[4] = {64, 128, 256, 512};
+  float* G0 = ws + p.G[0];
+  float* G1 = ws + p.G[1];
+  float* G2 = ws + p.G[2];
+  float* G3 = ws + p.G[3];
+  float* wg = ws + p.wg;
+  // d(out of last block) from the average pool
+  hipLaunchKernelGGL(avgpool_bwd, dim3(ew_grid(N * p.h[5] * p.w[5] * 512)), dim3(256), 0, s, dfeat, G0, d->N,
+                     p.h[5] * p.w[5], 512);
+  auto wgrad = [&](int i, const float* xin, const float* dyraw) -> int {
+    if (!g->conv_w[i]) return AVVAD_OK;
+    int r = conv_wgrad(xin, dyraw, wg, p.geom[i], s);
+    if (r) return r;
+    const ConvSpec& c = p.conv[i];
+    if (i == 0) hipLaunchKernelGGL(unpack_stem_wgrad, dim3(cdiv(64 * 147, 256)), dim3(256), 0, s, wg, g->conv_w[0]);
+    else hipLaunchKernelGGL(unpack_wgrad, dim3(ew_grid(c.cout * c.cin * c.ks * c.ks)), dim3(256), 0, s, wg, g->conv_w[i],
+                            c.cout, c.cin, c.ks);
+    return AVVAD_OK;
+  };
+  int ci = NCONV;
+  for (int st = 3; st >= 0; --st)
+    for (int b = 1; b >= 0; --b) {
+      const bool ds = (b == 0 && st > 0);
+      ci -= ds ? 3 : 2;
+      const int i1 = ci, i2 = ci + 1, id = ci + 2;
+      const size_t* o = p.blk[st * 2 + b];
+      const float* x = (st == 0 && b == 0) ? ws + p.p0 : (b == 1 ? ws + p.blk[st * 2][4] : ws + p.blk[st * 2 - 1][4]);
+      const long M = N * p.h[st + 2] * p.w[st + 2];
+      (void)widths;
+      // G0 = d(block output, post-ReLU).  main branch: BN2 backward (mask out>0) -> d c2 in G1
+      if (ds) {
+        if ((rc = bn_backward(&p, ws, i2, ws + o[2], G0, ws + o[4], G1, nullptr, M, prm, g, d, s))) return rc;
+        // identity branch through downsample BN + 1x1 conv: d cd in G2, d x in G3
+        if ((rc = bn_backward(&p, ws, id, ws + o[3], G0, ws + o[4], G2, nullptr, M, prm, g, d, s))) return rc;
+        if ((rc = wgrad(id, x, G2))) return rc;
+        if ((rc = conv_dgrad(G2, ws + p.wd[id], G3, p.geom[id], 0, s))) return rc;
+      } else {
+        // identity branch: d x = masked d out (written to G3 by the apply kernel)
+        if ((rc = bn_backward(&p, ws, i2, ws + o[2], G0, ws + o[4], G1, G3, M, prm, g, d, s))) return rc;
+      }
+      if ((rc = wgrad(i2, ws + o[1], G1))) return rc;
+      if ((rc = conv_dgrad(G1, ws + p.wd[i2], G2, p.geom[i2], 0, s))) return rc;  // d a1 in G2
+      if ((rc = bn_backward(&p, ws, i1, ws + o[0], G2, ws + o[1], G1, nullptr, M, prm, g, d, s))) return rc;  // d c1 in G1
+      if ((rc = wgrad(i1, x, G1))) return rc;
+      if ((rc = conv_dgrad(G1, ws + p.wd[i1], G3, p.geom[i1], 1, s))) return rc;  // d x += ...
+      float* t = G0; G0 = G3; G3 = t;
+    }
+  // stem: G0 = d p0
+  if (g->conv_w[0] || g->bn_w[0] || g->bn_b[0]) {
+    float* g0 = ws + p.g0;
+    hipLaunchKernelGGL(stem_pool_relu_bwd, dim3(ew_grid(N * p.h[1] * p.w[1] * 16)), dim3(256), 0, s, ws + p.c0,
+                       ws + p.bn_scale, ws + p.bn_shift, ws + p.p0, G0, g0, d->N, p.h[1], p.w[1], p.h[2], p.w[2]);
+    const long M0 = N * p.h[1] * p.w[1];
+    // in place: d c0 overwrites g0
+    if ((rc = bn_backward(&p, ws, 0, ws + p.c0, g0, nullptr, g0, nullptr, M0, prm, g, d, s))) return rc;
+    if ((rc = wgrad(0, frames, g0))) return rc;
+  }
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}

@@ -1,0 +1,369 @@
+// wavenet.hip -- WaveNet-style encoder (valid dilated Conv1d stack): forward and backward.
+//
+// Replaces wavenet_autoencoder._encode, packages/models/wavenet_autoencoder.py:74-93:
+//   s0 = causal(wave)                                            (:75)
+//   s_{i+1} = dense_i(relu(dil_i(relu(s_i)))) + s_i[:, :, -len:]   (:78-86)
+//   out = AdaptiveAvgPool1d(P)(relu(bottleneck(s_N)))            (:88-92)
+// Layout: [B][C][L] fp32, time contiguous (the reference's NCL).
+//
+// Production shape (R = D = 32, filter_width 2) runs a fused MFMA kernel per
+// residual block: one wave owns a 32-sample time tile; lane half h of the wave
+// streams tap h (x[c][t + h*d]) straight from HBM into the B operand of
+// v_mfma_f32_32x32x2_f32 -- the dilation gather is the lane-half assignment,
+// no LDS, no shuffles -- all 3072 block weights sit in registers as A
+// operands, and the first GEMM's accumulator tile (rows = dilation channels in
+// registers, column = time on the lane) is consumed in place as the B operand
+// of the 1x1 "dense" GEMM (k-order permuted to the accumulator's row order).
+// ReLUs, both biases and the left-cropped residual are fused; each activation
+// is read once (+ once for the residual, an L2 hit) and written once.
+// Any other (R, D, filter_width) runs generic direct kernels.
+// Weight gradients contract over (sequence, time) on the igemm engine.
+#include "gemm_api.h"
+
+namespace {
+
+static inline int grid1(long n) { long b = (n + 255) / 256; return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b)); }
+
+// ------------------------------------------------------------------ generic direct kernels
+// y[b][co][t] = bias[co] + sum_{ci,k} w[co][ci][k] * f(x[b][ci][t + k*dil])  (+ res[b][co][t + res_off])
+__global__ void conv1d_fwd_generic(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                   const float* __restrict__ res, float* __restrict__ y, int B, int Cin, int Cout, int Lin,
+                                   int Lout, int fw, int dil, int relu_in, int res_off, int res_L) {
+  const long n = (long)B * Cout * Lout;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % Lout);
+    const int co = (int)((i / Lout) % Cout);
+    const int b = (int)(i / ((long)Lout * Cout));
+    float acc = bias ? bias[co] : 0.f;
+    const float* xb = x + (long)b * Cin * Lin + t;
+    const float* wr = w + (long)co * Cin * fw;
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int k = 0; k < fw; ++k) {
+        float v = xb[(long)ci * Lin + k * dil];
+        if (relu_in) v = fmaxf(v, 0.f);
+        acc = fmaf(wr[ci * fw + k], v, acc);
+      }
+    if (res) acc += res[((long)b * Cout + co) * res_L + t + res_off];
+    y[i] = acc;
+  }
+}
+
+// dx[b][ci][ti] = mask(xmask>0) * sum_{co,k} w[co][ci][k] dy[b][co][ti - k*dil]   (+ res[b][ci][ti - res_off])
+__global__ void conv1d_bwd_data_generic(const float* __restrict__ dy, const float* __restrict__ w,
+                                        const float* __restrict__ xmask, const float* __restrict__ res, float* __restrict__ dx,
+                                        int B, int Cin, int Cout, int Lin, int Lout, int fw, int dil, int res_off, int res_L) {
+  const long n = (long)B * Cin * Lin;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int ti = (int)(i % Lin);
+    const int ci = (int)((i / Lin) % Cin);
+    const int b = (int)(i / ((long)Lin * Cin));
+    float acc = 0.f;
+    if (!xmask || xmask[i] > 0.f) {
+      for (int k = 0; k < fw; ++k) {
+        const int to = ti - k * dil;
+        if (to < 0 || to >= Lout) continue;
+        const float* dyb = dy + (long)b * Cout * Lout + to;
+        for (int co = 0; co < Cout; ++co) acc = fmaf(w[((long)co * Cin + ci) * fw + k], dyb[(long)co * Lout], acc);
+      }
+    }
+    if (res && ti >= res_off && ti - res_off < res_L) acc += res[((long)b * Cin + ci) * res_L + ti - res_off];
+    dx[i] = acc;
+  }
+}
+
+// db[c] += sum_{b,t} dy[b][c][t]
+__global__ void __launch_bounds__(256) chan_sum_acc(const float* __restrict__ dy, float* __restrict__ db, int B, int C, int L) {
+  __shared__ float sm[256];
+  const int c = blockIdx.x;
+  float s = 0.f;
+  for (int b = blockIdx.y; b < B; b += gridDim.y) {
+    const float* p = dy + ((long)b * C + c) * L;
+    for (int t = threadIdx.x; t < L; t += 256) s += p[t];
+  }
+  sm[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(db + c, sm[0]);
+}
+
+__device__ __forceinline__ void pool_bin(int p, int Lv, int P, int& a, int& e) {
+  a = (int)(((long)p * Lv) / P);
+  e = (int)((((long)(p + 1)) * Lv + P - 1) / P);
+}
+
+// out[b][bn][p] = mean_{t in bin p} relu(bb[bn] + sum_c Wb[bn][c] s[b][c][t])
+__global__ void __launch_bounds__(256)
+    tail_fwd_generic(const float* __restrict__ s, const float* __restrict__ wb, const float* __restrict__ bb,
+                     float* __restrict__ out, int R, int Bn, int Lv, int P) {
+  const int b = blockIdx.y, p = blockIdx.x;
+  int a, e;
+  pool_bin(p, Lv, P, a, e);
+  const float* sb = s + (long)b * R * Lv;
+  for (int bn = threadIdx.x; bn < Bn; bn += 256) {
+    const float* wr = wb + (long)bn * R;
+    const float bias = bb ? bb[bn] : 0.f;
+    float sum = 0.f;
+    for (int t = a; t < e; ++t) {
+      float z = bias;
+      for (int c = 0; c < R; ++c) z = fmaf(wr[c], sb[(long)c * Lv + t], z);
+      sum += fmaxf(z, 0.f);
+    }
+    out[((long)b * Bn + bn) * P + p] = sum / (float)(e - a);
+  }
+}
+
+// dz[b][bn][t] = (z>0) * sum_{p: t in bin p} dout[b][bn][p] / len_p
+__global__ void tail_bwd_dz_generic(const float* __restrict__ s, const float* __restrict__ wb, const float* __restrict__ bb,
+                                    const float* __restrict__ dout, float* __restrict__ dz, int B, int R, int Bn, int Lv, int P) {
+  const long n = (long)B * Bn * Lv;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int t = (int)(i % Lv);
+    const int bn = (int)((i / Lv) % Bn);
+    const int b = (int)(i / ((long)Lv * Bn));
+    float z = bb ? bb[bn] : 0.f;
+    const float* sb = s + (long)b * R * Lv + t;
+    for (int c = 0; c < R; ++c) z = fmaf(wb[(long)bn * R + c], sb[(long)c * Lv], z);
+    float g = 0.f;
+    if (z > 0.f) {
+      const int pc = (int)(((long)t * P) / Lv);
+      for (int p = max(0, pc - 1); p <= min(P - 1, pc + 1); ++p) {
+        int a, e;
+        pool_bin(p, Lv, P, a, e);
+        if (t >= a && t < e) g += dout[((long)b * Bn + bn) * P + p] / (float)(e - a);
+      }
+    }
+    dz[i] = g;
+  }
+}
+
+// ------------------------------------------------------------------ fused MFMA residual block (R = D = 32, fw = 2)
+// MODE 0: write s_out only; MODE 1: write s_out and z (pre-ReLU dilation output); MODE 2: write z only
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    wn_block_fwd_mfma(const float* __restrict__ s_in, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
+                      const float* __restrict__ w_dense, const float* __restrict__ b_dense, float* __restrict__ s_out,
+                      float* __restrict__ z_out, int B, int Lin, int dil) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+
+  // A operands, resident for the whole kernel
+  float wd[32];   // W_dil[d = li][c = s][tap = lh]
+#pragma unroll
+  for (int s = 0; s < 32; ++s) wd[s] = w_dil[(li * 32 + s) * 2 + lh];
+  float we[16];   // W_dense[r = li][d = row(r', lh)]
+  float bz[16], bs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mfma32_row(r, lh);
+    we[r] = w_dense[li * 32 + row];
+    bz[r] = b_dil ? b_dil[row] : 0.f;
+    bs[r] = b_dense ? b_dense[row] : 0.f;
+  }
+
+  for (long tile = wave0; tile < ntiles; tile += nwaves) {
+    const int b = (int)(tile / tiles_per_seq);
+    const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lo;
+    const float* xp = s_in + (long)b * 32 * Lin + t + lh * dil;
+    float x[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = ok ? xp[(long)c * Lin] : 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bz[r];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = mfma32(wd[s], fmaxf(x[s], 0.f), acc);
+    if (MODE >= 1) {
+      float* zp = z_out + (long)b * 32 * Lo + t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ok) zp[(long)mfma32_row(r, lh) * Lo] = acc[r];
+    }
+    if (MODE <= 1) {
+      const float* rp = s_in + (long)b * 32 * Lin + t + dil;
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = bs[r] + (ok ? rp[(long)mfma32_row(r, lh) * Lin] : 0.f);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2 = mfma32(we[r], fmaxf(acc[r], 0.f), acc2);
+      float* op = s_out + (long)b * 32 * Lo + t;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (ok) op[(long)mfma32_row(r, lh) * Lo] = acc2[r];
+    }
+  }
+}
+
+// ------------------------------------------------------------------ plan / workspace
+struct Plan {
+  int n;
+  int L[66];        // L[0] = causal output length, L[i+1] = after block i
+  size_t s[66];     // offsets of s_i (floats); without save_for_backward only 2 ping-pong buffers
+  size_t z, dz, ga, gb, dzt;
+  size_t total;
+};
+static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
+  if (!d || d->n_layers < 0 || d->n_layers > 64 || d->B <= 0 || d->fw < 1 || d->qc < 1 || d->R < 1 || d->D < 1 ||
+      d->Bn < 1 || d->P < 1 || (d->n_layers > 0 && !d->dilations_h))
+    return AVVAD_EINVAL;
+  p->n = d->n_layers;
+  p->L[0] = d->L - (d->fw - 1);
+  for (int i = 0; i < p->n; ++i) p->L[i + 1] = p->L[i] - d->dilations_h[i] * (d->fw - 1);
+  if (p->L[p->n] < 1) return AVVAD_EINVAL;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return o; };
+  const size_t B = d->B;
+  if (d->save_for_backward) {
+    for (int i = 0; i <= p->n; ++i) p->s[i] = take(B * d->R * p->L[i]);
+    const size_t big = B * (size_t)(d->R > d->D ? d->R : d->D) * p->L[0];
+    p->z = take(big); p->dz = take(big); p->ga = take(big); p->gb = take(big);
+    p->dzt = take(B * d->Bn * p->L[p->n]);
+  } else {
+    const size_t a = take(B * d->R * p->L[0]), b2 = take(B * d->R * p->L[0]);
+    for (int i = 0; i <= p->n; ++i) p->s[i] = (i & 1) ? b2 : a;
+    p->z = take(B * d->D * p->L[0]);  // scratch of the generic (non-MFMA-shape) block path
+    p->dz = p->ga = p->gb = p->dzt = 0;
+  }
+  p->total = off;
+  return AVVAD_OK;
+}
+
+static inline bool mfma_shape(const avvad_wavenet_desc* d) { return d->R == 32 && d->D == 32 && d->fw == 2; }
+
+// dw[co][ci][k] += sum_{b,t} dy[b][co][t] * f(x[b][ci][t + k*dil])  for every tap, on the engine
+static int wgrad_conv1d(const float* dy, const float* x, float* dw, int B, int Cout, int Cin, int Lout, int Lin, int fw,
+                        int dil, int relu_in, hipStream_t s) {
+  const long K = (long)B * Lout;
+  if (K > 0x7fffffffL) return AVVAD_EINVAL;
+  const int ktiles = cdiv(K, igemm::BK);
+  int split = 1024 / (cdiv(Cout, 64) * cdiv(Cin, 64));
+  if (split > ktiles) split = ktiles;
+  if (split < 1) split = 1;
+  for (int k = 0; k < fw; ++k) {
+    igemm::RowSegK a{dy, Lout, (long)Cout * Lout, Cout, (int)K, Lout, 0, 0};
+    igemm::RowSegK b{x, Lin, (long)Cin * Lin, Cin, (int)K, Lout, k * dil, relu_in};
+    igemm::EpiStore e{dw + k, (long)Cin * fw, nullptr, 2, fw};
+    int rc = igemm::launch<64, 64>(a, b, e, Cout, Cin, (int)K, split, s);
+    if (rc) return rc;
+  }
+  return AVVAD_OK;
+}
+
+static void bias_grad(const float* dy, float* db, int B, int C, int L, hipStream_t s) {
+  if (!db) return;
+  hipLaunchKernelGGL(chan_sum_acc, dim3(C, B < 64 ? B : 64), dim3(256), 0, s, dy, db, B, C, L);
+}
+
+}  // namespace
+
+extern "C" size_t avvad_wavenet_workspace(const avvad_wavenet_desc* d) {
+  Plan p;
+  if (make_plan(d, &p)) return 0;
+  return p.total * sizeof(float);
+}
+
+extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* prm, float* out, const avvad_wavenet_desc* d,
+                                 void* wsv, size_t ws_bytes, avvad_stream_t sv) {
+  Plan p;
+  if (!wave || !prm || !out || !wsv || make_plan(d, &p)) return AVVAD_EINVAL;
+  if (ws_bytes < p.total * sizeof(float)) return AVVAD_EWORKSPACE;
+  hipStream_t s = (hipStream_t)sv;
+  float* ws = (float*)wsv;
+  const int B = d->B, R = d->R, D = d->D, fw = d->fw;
+  // causal layer: Conv1d(qc -> R, k = fw), no input ReLU   (:75)
+  hipLaunchKernelGGL(conv1d_fwd_generic, dim3(grid1((long)B * R * p.L[0])), dim3(256), 0, s, wave, prm->causal_w,
+                     d->use_bias ? prm->causal_b : (const float*)nullptr, (const float*)nullptr, ws + p.s[0], B, d->qc, R,
+                     d->L, p.L[0], fw, 1, 0, 0, 0);
+  for (int i = 0; i < p.n; ++i) {
+    const int dil = d->dilations_h[i];
+    const float* bd = d->use_bias ? prm->dil_b_h[i] : nullptr;
+    const float* be = d->use_bias ? prm->dense_b_h[i] : nullptr;
+    if (mfma_shape(d)) {
+      const long ntiles = (long)B * cdiv(p.L[i + 1], 32);
+      long blocks = (ntiles + 3) / 4;
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
+                         prm->dense_w_h[i], be, ws + p.s[i + 1], (float*)nullptr, B, p.L[i], dil);
+    } else {
+      float* z = ws + p.z;
+      hipLaunchKernelGGL(conv1d_fwd_generic, dim3(grid1((long)B * D * p.L[i + 1])), dim3(256), 0, s, ws + p.s[i],
+                         prm->dil_w_h[i], bd, (const float*)nullptr, z, B, R, D, p.L[i], p.L[i + 1], fw, dil, 1, 0, 0);
+      hipLaunchKernelGGL(conv1d_fwd_generic, dim3(grid1((long)B * R * p.L[i + 1])), dim3(256), 0, s, z, prm->dense_w_h[i], be,
+                         ws + p.s[i], ws + p.s[i + 1], B, D, R, p.L[i + 1], p.L[i + 1], 1, 1, 1, p.L[i] - p.L[i + 1], p.L[i]);
+    }
+  }
+  hipLaunchKernelGGL(tail_fwd_generic, dim3(d->P, B), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,
+                     d->use_bias ? prm->bott_b : (const float*)nullptr, out, R, d->Bn, p.L[p.n], d->P);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* prm, const float* dout,
+                                 const avvad_wavenet_grads* g, float* dwave, const avvad_wavenet_desc* d, void* wsv,
+                                 size_t ws_bytes, avvad_stream_t sv) {
+  Plan p;
+  if (!wave || !prm || !dout || !g || !wsv || make_plan(d, &p) || !d->save_for_backward) return AVVAD_EINVAL;
+  if (ws_bytes < p.total * sizeof(float)) return AVVAD_EWORKSPACE;
+  hipStream_t s = (hipStream_t)sv;
+  float* ws = (float*)wsv;
+  const int B = d->B, R = d->R, D = d->D, fw = d->fw, Bn = d->Bn;
+  int rc;
+  const int Lv = p.L[p.n];
+  float* Z = ws + p.z;
+  float* DZ = ws + p.dz;
+  float* GA = ws + p.ga;  // d s_{i+1}
+  float* GB = ws + p.gb;  // d s_i
+  // ---- tail: dz_t = relu'(z) * pooled-grad ; d s_N = Wb^T dz_t
+  float* DZT = ws + p.dzt;
+  hipLaunchKernelGGL(tail_bwd_dz_generic, dim3(grid1((long)B * Bn * Lv)), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,
+                     d->use_bias ? prm->bott_b : (const float*)nullptr, dout, DZT, B, R, Bn, Lv, d->P);
+  if (g->bott_w && (rc = wgrad_conv1d(DZT, ws + p.s[p.n], g->bott_w, B, Bn, R, Lv, Lv, 1, 1, 0, s))) return rc;
+  if (d->use_bias) bias_grad(DZT, g->bott_b, B, Bn, Lv, s);
+  hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Lv)), dim3(256), 0, s, DZT, prm->bott_w,
+                     (const float*)nullptr, (const float*)nullptr, GA, B, R, Bn, Lv, Lv, 1, 1, 0, 0);
+  // ---- residual blocks, last to first
+  for (int i = p.n - 1; i >= 0; --i) {
+    const int dil = d->dilations_h[i];
+    const int Li = p.L[i], Lo = p.L[i + 1];
+    const float* si = ws + p.s[i];
+    const float* bd = d->use_bias ? prm->dil_b_h[i] : nullptr;
+    // recompute z = dil_i(relu(s_i)) (pre-ReLU)
+    if (mfma_shape(d)) {
+      const long ntiles = (long)B * cdiv(Lo, 32);
+      long blocks = (ntiles + 3) / 4;
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL(wn_block_fwd_mfma<2>, dim3((int)blocks), dim3(256), 0, s, si, prm->dil_w_h[i], bd,
+                         prm->dense_w_h[i], (const float*)nullptr, (float*)nullptr, Z, B, Li, dil);
+    } else {
+      hipLaunchKernelGGL(conv1d_fwd_generic, dim3(grid1((long)B * D * Lo)), dim3(256), 0, s, si, prm->dil_w_h[i], bd,
+                         (const float*)nullptr, Z, B, R, D, Li, Lo, fw, dil, 1, 0, 0);
+    }
+    // dense (1x1) layer: d W_dense = GA . relu(z)^T ; d b ; dz = (z>0) * W_dense^T GA
+    if (g->dense_w_h[i] && (rc = wgrad_conv1d(GA, Z, g->dense_w_h[i], B, R, D, Lo, Lo, 1, 1, 1, s))) return rc;
+    if (d->use_bias) bias_grad(GA, g->dense_b_h[i], B, R, Lo, s);
+    hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * D * Lo)), dim3(256), 0, s, GA, prm->dense_w_h[i], Z,
+                       (const float*)nullptr, DZ, B, D, R, Lo, Lo, 1, 1, 0, 0);
+    // dilated layer: d W_dil = dz . relu(s_i shifted)^T ; d b ; d s_i = (s_i>0) * W_dil^T (*) dz + left-padded GA
+    if (g->dil_w_h[i] && (rc = wgrad_conv1d(DZ, si, g->dil_w_h[i], B, D, R, Lo, Li, fw, dil, 1, s))) return rc;
+    if (d->use_bias) bias_grad(DZ, g->dil_b_h[i], B, D, Lo, s);
+    hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Li)), dim3(256), 0, s, DZ, prm->dil_w_h[i], si, GA,
+                       GB, B, R, D, Li, Lo, fw, dil, Li - Lo, Lo);
+    float* t = GA; GA = GB; GB = t;
+  }
+  // ---- causal layer
+  if (g->causal_w && (rc = wgrad_conv1d(GA, wave, g->causal_w, B, R, d->qc, p.L[0], d->L, fw, 1, 0, s))) return rc;
+  if (d->use_bias) bias_grad(GA, g->causal_b, B, R, p.L[0], s);
+  if (dwave)
+    hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * d->qc * d->L)), dim3(256), 0, s, GA, prm->causal_w,
+                       (const float*)nullptr, (const float*)nullptr, dwave, B, d->qc, R, d->L, p.L[0], fw, 1, 0, 0);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}

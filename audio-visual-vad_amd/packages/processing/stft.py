@@ -1,0 +1,36 @@
+"""Drop-in for ``stft_pytorch`` of ``packages/processing/stft.py:102-151`` (the librosa twins of that file are
+off the hot path).  Same signature and legacy return layout (bins, frames, 2) = (re, im).
+
+The reference calls ``torch.stft`` without ``return_complex`` (an error on torch >= 2); this version asks for
+the complex result and returns its real view.  Framing/windowing: optional zero pad of one hop at the end
+when the utterance is not a whole number of hops, periodic Hann of the FFT length, ``center`` as given."""
+import math
+
+import torch
+
+
+def stft_pytorch(x, fs=16e3, wlen_sec=50e-3, win='hann', hop_percent=0.25, center=True, pad_mode='reflect',
+                 pad_at_end=True):
+    if wlen_sec * fs != int(wlen_sec * fs):
+        raise ValueError("wlen_sample of STFT is not an integer.")
+    nfft = int(wlen_sec * fs)
+    hopsamp = int(hop_percent * nfft)
+    x_ = x
+    if pad_at_end:
+        n_hops = len(x) / fs / wlen_sec / hop_percent
+        if math.ceil(n_hops) != int(n_hops):
+            x_ = torch.nn.functional.pad(x, (0, hopsamp), mode='constant')
+    if isinstance(win, str):
+        if win != 'hann':
+            raise ValueError("only the Hann window is supported")
+        window = torch.hann_window(window_length=nfft, device=x.device)
+    else:
+        window = win
+    S = torch.stft(input=x_, n_fft=nfft, hop_length=hopsamp, win_length=None, window=window, center=center,
+                   pad_mode=pad_mode, return_complex=True)
+    return torch.view_as_real(S)
+
+
+def log_power(S, eps=1e-8):
+    """|X|^2 -> log(. + eps): the callers' post-processing (scripts/evaluate_audio_net.py:141-148)."""
+    return torch.log(S[..., 0] ** 2 + S[..., 1] ** 2 + eps)

@@ -1,0 +1,220 @@
+/* avvad.h -- C ABI of libavvad_hip.so: the MI355X (gfx950) kernels behind the
+ * per-frame classification hot path of sp-uhh/audio-visual-vad.
+ *
+ * The reference has no FFI / operator registry (it is pure Python on torch.nn,
+ * SURVEY.md 8b); every entry point below replaces a stock torch / torchvision
+ * call site of the reference, cited as file:line relative to the reference root.
+ * The Python host (audio-visual-vad_amd/avvad) binds these with ctypes; a
+ * maintainer of the reference would add the same ctypes stub.
+ *
+ * Conventions (all entry points):
+ *   - plain C types only; every pointer is a DEVICE pointer unless the
+ *     parameter name ends in _h (host);
+ *   - the caller allocates every buffer, including the workspace
+ *     (size from the matching *_workspace() query, bytes);
+ *   - asynchronous on the given hipStream_t, never synchronises, never
+ *     allocates; no hidden state -> re-entrant across streams and devices,
+ *     capturable into a hipGraph;
+ *   - returns AVVAD_OK or a negative AVVAD_E* code, never throws;
+ *   - fp32 storage and fp32 arithmetic (fp32-input MFMA == ordered fmaf chain).
+ */
+#ifndef AVVAD_H
+#define AVVAD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* avvad_stream_t; /* hipStream_t */
+
+#define AVVAD_OK 0
+#define AVVAD_EINVAL (-1)     /* bad descriptor / unsupported shape */
+#define AVVAD_EWORKSPACE (-2) /* workspace too small */
+#define AVVAD_ELAUNCH (-3)    /* hipGetLastError() != hipSuccess after a launch */
+
+/* library / build identification ("gfx950", ABI version) */
+const char* avvad_version(void);
+int avvad_abi_version(void);
+
+/* ------------------------------------------------------------------------
+ * Dense GEMM on fp32 MFMA:  C[M,N] (+)= op(A) . op(B) (+ bias[N])
+ *   transA=0: A is [M,K] row-major (lda);  transA=1: A is stored [K,M] (lda)
+ *   transB=0: B is [K,N] row-major (ldb);  transB=1: B is stored [N,K] (ldb)
+ *   accumulate: C += result (needed when split_k > 1: partials are added with
+ *   float atomics onto the existing C).
+ * Replaces: nn.LSTM input / recurrent projections and nn.Linear
+ *   (packages/models/Audio_Net.py:30-35,51-59, Video_Net.py:45-51,102-116,
+ *    AV_Net.py:53-58,128-140) and their autograd backward.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int M, N, K;
+  int lda, ldb, ldc;
+  int transA, transB;
+  int accumulate;
+  int split_k; /* >= 1 */
+  int relu_a;  /* apply max(.,0) to A elements on load */
+  int relu_b;
+} avvad_gemm_desc;
+int avvad_gemm_f32(const float* A, const float* B, const float* bias, float* C,
+                   const avvad_gemm_desc* d, avvad_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * WaveNet-style encoder (valid dilated Conv1d stack)
+ * Replaces: wavenet_autoencoder._encode, packages/models/wavenet_autoencoder.py:74-93
+ * Layout: activations [B][C][L] (torch NCL, time contiguous); weights exactly as
+ * in the state_dict: Conv1d weight [Cout][Cin][fw], bias [Cout].
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int B;   /* sequences                                                */
+  int L;   /* input samples per sequence                               */
+  int qc;  /* quantization_channel (input channels)                    */
+  int R;   /* en_residual_channel                                      */
+  int D;   /* en_dilation_channel                                      */
+  int Bn;  /* en_bottleneck_width                                      */
+  int fw;  /* filter_width                                             */
+  int P;   /* en_pool_kernel_size (used as pool OUTPUT size, :91)      */
+  int n_layers;
+  const int* dilations_h; /* host array [n_layers]                     */
+  int use_bias;
+  int save_for_backward; /* forward keeps s_i and z_i in the workspace */
+} avvad_wavenet_desc;
+
+/* parameter pointers, host arrays of device pointers */
+typedef struct {
+  const float* causal_w;
+  const float* causal_b;
+  const float* const* dil_w_h; /* [n_layers] */
+  const float* const* dil_b_h;
+  const float* const* dense_w_h;
+  const float* const* dense_b_h;
+  const float* bott_w;
+  const float* bott_b;
+} avvad_wavenet_params;
+
+typedef struct {
+  float* causal_w;
+  float* causal_b;
+  float* const* dil_w_h;
+  float* const* dil_b_h;
+  float* const* dense_w_h;
+  float* const* dense_b_h;
+  float* bott_w;
+  float* bott_b;
+} avvad_wavenet_grads;
+
+size_t avvad_wavenet_workspace(const avvad_wavenet_desc* d);
+/* wave [B][qc][L] -> out [B][Bn][P] */
+int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* p, float* out,
+                      const avvad_wavenet_desc* d, void* ws, size_t ws_bytes, avvad_stream_t s);
+/* needs the workspace of a forward run with save_for_backward=1.
+ * grads are ACCUMULATED (+=) into g; dwave may be NULL. */
+int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* p, const float* dout,
+                      const avvad_wavenet_grads* g, float* dwave, const avvad_wavenet_desc* d,
+                      void* ws, size_t ws_bytes, avvad_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * ResNet-18 trunk over gray lip crops
+ * Replaces: self.features(video).squeeze() with the 3x channel repeat in front,
+ *   packages/models/Video_Net.py:60-81, packages/models/AV_Net.py:78-94
+ *   (torchvision.models.resnet18 children [:-1]).
+ * Layout: input frames [N][H][W] (1 channel; the reference's 3 identical
+ * channels are folded into conv1's weights), activations NHWC inside, output
+ * [N][512].  Parameters are passed in torchvision state_dict layout (OIHW).
+ * ---------------------------------------------------------------------- */
+#define AVVAD_TRUNK_NCONV 20 /* conv1 + 16 block convs + 3 downsample convs */
+
+typedef struct {
+  int N, H, W;
+  int training;   /* batch statistics + running-stat update */
+  float momentum; /* 0.1 */
+  float eps;      /* 1e-5 */
+  int save_for_backward;
+} avvad_trunk_desc;
+
+/* conv index order: 0 = conv1; then per stage s (0..3), per block b (0..1):
+ * conv1, conv2, [downsample if s>0 and b==0].  The i-th BatchNorm follows the
+ * i-th conv.  (torchvision order: features.0/1, features.{4..7}.{0,1}.{conv1,bn1,conv2,bn2,downsample}) */
+typedef struct {
+  const float* conv_w[AVVAD_TRUNK_NCONV]; /* OIHW */
+  const float* bn_w[AVVAD_TRUNK_NCONV];
+  const float* bn_b[AVVAD_TRUNK_NCONV];
+  float* bn_rm[AVVAD_TRUNK_NCONV]; /* running_mean (updated when training) */
+  float* bn_rv[AVVAD_TRUNK_NCONV]; /* running_var                          */
+} avvad_trunk_params;
+
+typedef struct {
+  float* conv_w[AVVAD_TRUNK_NCONV]; /* OIHW, accumulated (+=) */
+  float* bn_w[AVVAD_TRUNK_NCONV];
+  float* bn_b[AVVAD_TRUNK_NCONV];
+} avvad_trunk_grads;
+
+size_t avvad_trunk_workspace(const avvad_trunk_desc* d);
+int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* p, float* feat /* [N][512] */,
+                    const avvad_trunk_desc* d, void* ws, size_t ws_bytes, avvad_stream_t s);
+int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* p, const float* dfeat,
+                    const avvad_trunk_grads* g, const avvad_trunk_desc* d, void* ws, size_t ws_bytes,
+                    avvad_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Packed-sequence multi-layer LSTM (unidirectional) -- batch_first padded input,
+ * padded output steps are zero, (h,c) stop at each sequence's length.
+ * Replaces: pack_padded_sequence -> nn.LSTM -> pad_packed_sequence(total_length)
+ *   packages/models/Audio_Net.py:50-56, Video_Net.py:102-113, AV_Net.py:127-137
+ * x [B][T][In], y [B][T][H]; weights in state_dict layout: w_ih [4H][In],
+ * w_hh [4H][H], b_ih/b_hh [4H], gate order i,f,g,o.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int B, T, In, H;
+  const int* lengths; /* device int32 [B] */
+  int save_for_backward;
+} avvad_lstm_desc;
+size_t avvad_lstm_workspace(const avvad_lstm_desc* d);
+int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
+                         const float* b_hh, float* y, const avvad_lstm_desc* d, void* ws,
+                         size_t ws_bytes, avvad_stream_t s);
+/* dx may be NULL; parameter grads are accumulated (+=). dy is [B][T][H]. */
+int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const float* w_hh, const float* y,
+                         const float* dy, float* dx, float* dw_ih, float* dw_hh, float* db_ih,
+                         float* db_hh, const avvad_lstm_desc* d, void* ws, size_t ws_bytes,
+                         avvad_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Masked BCE-with-eps loss, summed over sequences
+ * Replaces: binary_cross_entropy packages/models/utils.py:108-113 and its caller
+ *   loop scripts/train_AV_net.py:298-301  (per-sequence mean over valid frames
+ *   and y_dim, summed over the batch).
+ * logits/targets [B][T][Y]; loss: one float (overwritten); dlogits [B][T][Y]
+ * (d loss / d logits, zero on padded steps), may be NULL.
+ * ---------------------------------------------------------------------- */
+int avvad_bce_masked(const float* logits, const float* targets, const int* lengths, float* loss,
+                     float* dlogits, int B, int T, int Y, float eps, avvad_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Fused Adam step over a flat parameter buffer
+ * Replaces: torch.optim.Adam(lr, betas=(0.9,0.999)).step()  scripts/train_AV_net.py:238,306
+ * (torch semantics: eps added to sqrt(v_hat); no weight decay, no amsgrad).
+ * ---------------------------------------------------------------------- */
+int avvad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n,
+                    float lr, float beta1, float beta2, float eps, int step, avvad_stream_t s);
+
+/* ------------------------------------------------------------------------
+ * Small fused elementwise helpers used by the Python host
+ * ---------------------------------------------------------------------- */
+/* dst[r][dst_off + c] = src[r][src_off + c], c < ncols (row strides src_ld / dst_ld) -- writes a
+ * branch into the concat buffer (torch.cat, AV_Net.py:124) and splits its gradient back */
+int avvad_copy_cols(const float* src, float* dst, size_t rows, int ncols, int src_ld, int src_off,
+                    int dst_ld, int dst_off, avvad_stream_t s);
+/* out[c] += sum_r X[r][c]   (bias gradient of nn.Linear) */
+int avvad_colsum_acc(const float* X, size_t rows, int cols, float* out, avvad_stream_t s);
+/* x[i] *= *scalar  (scalar lives on the device: upstream gradient of the loss) */
+int avvad_scale_by_device_scalar(float* x, const float* scalar, size_t n, avvad_stream_t s);
+/* out[b][t][c] = in[b][c][t]  (encoder output (B,Bn,P) -> (B,P,Bn)) and back */
+int avvad_transpose_last2(const float* in, float* out, int B, int C, int T, avvad_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AVVAD_H */

@@ -1,0 +1,275 @@
+"""GPU parity tests: the HIP path (through the C ABI of libavvad_hip.so) against the CPU oracle and
+the golden vectors produced by the reference.  Tolerance: fp32, |delta| <= 1e-4 on outputs
+(BASELINE.json north_star); gradients are compared with a relative bound of the same order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import stategen
+from conftest import load_golden, wn_cfg_from
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = "cuda:0"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _report(name, got, ref, atol, rtol=0.0):
+    got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    ref = ref.detach().cpu().numpy() if isinstance(ref, torch.Tensor) else np.asarray(ref)
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    err = np.abs(got - ref)
+    bound = atol + rtol * np.abs(ref)
+    worst = float((err - bound).max()) if err.size else 0.0
+    msg = "%-44s max|d|=%.3e  max|ref|=%.3e  bound=%.1e+%.1e*|ref|" % (name, err.max() if err.size else 0, np.abs(ref).max() if ref.size else 0, atol, rtol)
+    print(msg)
+    try:
+        os.makedirs(OUT, exist_ok=True)
+        with open(os.path.join(OUT, "parity.log"), "a") as f:
+            f.write(msg + "\n")
+    except OSError:
+        pass
+    assert np.isfinite(got).all(), name + ": non-finite values"
+    assert worst <= 0, msg
+
+
+def _grad_tol(ref):
+    return 1e-4 * max(1.0, float(np.abs(ref).max()))
+
+
+# ------------------------------------------------------------------------------------------ GEMM engine
+@pytest.mark.parametrize("M,N,K,tA,tB", [(128, 128, 64, 0, 1), (100, 70, 513, 0, 1), (64, 4096, 1024, 0, 1),
+                                          (37, 130, 96, 0, 0), (130, 64, 40, 1, 0), (4096, 513, 48, 1, 0),
+                                          (48, 1, 1024, 0, 1), (1025, 300, 7, 1, 1), (256, 256, 4096, 0, 0)])
+def test_gemm_variants(M, N, K, tA, tB):
+    from avvad import ops
+    rng = np.random.RandomState(M + N + K)
+    A = rng.normal(size=(K, M) if tA else (M, K)).astype(np.float32)
+    B = rng.normal(size=(N, K) if tB else (K, N)).astype(np.float32)
+    bias = rng.normal(size=(N,)).astype(np.float32)
+    ref = (A.T if tA else A).astype(np.float64) @ (B.T if tB else B).astype(np.float64)
+    a, b, bs = T(A).to(DEV), T(B).to(DEV), T(bias).to(DEV)
+    c = torch.empty(M, N, device=DEV)
+    ops.gemm(a, b, c, M, N, K, A.shape[1], B.shape[1], N, bool(tA), bool(tB), bias=bs)
+    _report("gemm %dx%dx%d tA%d tB%d +bias" % (M, N, K, tA, tB), c, ref + bias, 1e-5 * np.sqrt(K) * 4)
+    c0 = torch.randn(M, N, device=DEV)
+    c1 = c0.clone()
+    ops.gemm(a, b, c1, M, N, K, A.shape[1], B.shape[1], N, bool(tA), bool(tB), accumulate=True, split_k=4)
+    _report("gemm %dx%dx%d split-k accumulate" % (M, N, K), c1, ref + c0.cpu().numpy(), 1e-5 * np.sqrt(K) * 4)
+
+
+# ------------------------------------------------------------------------------------------ WaveNet encoder
+@pytest.mark.parametrize("name", ["wn_tiny", "wn_fw3_qc2", "wn_nobias", "wn_w0", "wn_w0_t16"])
+def test_wavenet_golden(name):
+    from packages.models.wavenet_autoencoder import wavenet_autoencoder
+    g = load_golden(name)
+    cfg = wn_cfg_from(g)
+    m = wavenet_autoencoder(**cfg)
+    m.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("p.")})
+    m = m.to(DEV)
+    x = T(g["x"]).to(DEV).requires_grad_(True)
+    y = m(x)
+    _report(name + " forward", y, g["y"], 1e-4)
+    (y * T(g["G"]).to(DEV)).sum().backward()
+    _report(name + " d/dx", x.grad, g["dx"], _grad_tol(g["dx"]))
+    for k, p in m.named_parameters():
+        _report(name + " d/d" + k, p.grad, g["g." + k], _grad_tol(g["g." + k]))
+
+
+def test_wavenet_batch_and_tails():
+    """ragged tile tails (L not a multiple of 32) and B>1 on the MFMA block path vs the oracle."""
+    from oracle import wavenet as ow
+    from packages.models.wavenet_autoencoder import wavenet_autoencoder
+    cfg = dict(filter_width=2, quantization_channel=1, dilations=[1, 2, 4, 8, 16, 3], en_residual_channel=32,
+               en_dilation_channel=32, en_bottleneck_width=48, en_pool_kernel_size=7, use_bias=True)
+    torch.manual_seed(3)
+    m = wavenet_autoencoder(**cfg)
+    x = torch.randn(5, 1, 333)
+    ref = ow.encode({k: v.detach() for k, v in m.state_dict().items()}, x, cfg)
+    _report("wavenet ragged tails B=5 L=333", m.to(DEV)(x.to(DEV)), ref, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ heads
+@pytest.mark.parametrize("name,seed", [("audio_l2_h16", 1), ("audio_l1_h32_y3", 2)])
+def test_audio_net_golden(name, seed):
+    from packages.models.Audio_Net import DeepVAD_audio
+    from packages.models.utils import batch_binary_cross_entropy
+    g = load_golden(name)
+    L, H, ydim = [int(v) for v in g["meta"]]
+    m = DeepVAD_audio(L, H, ydim)
+    m.load_state_dict(stategen.make_state(stategen.lstm_spec("lstm_audio.", 513, H, L) +
+                                          stategen.linear_spec("vad_audio", H, ydim), seed))
+    m = m.to(DEV)
+    x = T(g["x"]).to(DEV).requires_grad_(True)
+    lens = g["lengths"].tolist()
+    y = m(x, lens)
+    _report(name + " logits", y, g["y"], 1e-4)
+    loss = batch_binary_cross_entropy(y, T(g["target"]).to(DEV), torch.LongTensor(lens), 1e-8)
+    _report(name + " loss", loss, g["loss"], 1e-4)
+    loss.backward()
+    _report(name + " d/dx", x.grad, g["dx"], _grad_tol(g["dx"]))
+    for k, p in m.named_parameters():
+        _report(name + " d/d" + k, p.grad, g["g." + k], _grad_tol(g["g." + k]))
+
+
+def test_lstm_full_size():
+    """production head size (H=1024, 2 layers, In=768) against the oracle's explicit time loop."""
+    from avvad import ops
+    from oracle import head
+    import torch.nn as nn
+    torch.manual_seed(0)
+    lstm = nn.LSTM(768, 1024, 2)
+    x = torch.randn(4, 6, 768)
+    lens = [6, 3, 5, 1]
+    sd = {k: v.detach() for k, v in lstm.state_dict().items()}
+    ref = head.lstm_stack(x, lens, sd, "", 2)
+    y = ops.lstm_stack(x.to(DEV), lens, lstm.to(DEV))
+    _report("lstm 2x1024 In=768", y, ref, 1e-4)
+
+
+def test_bce_and_metrics():
+    from packages.models.utils import binary_cross_entropy, f1_loss
+    g = load_golden("misc")
+    r = T(g["bce_r"]).to(DEV).requires_grad_(True)
+    loss = binary_cross_entropy(r, T(g["bce_x"]).to(DEV), 1e-8)
+    _report("bce", loss, g["bce"], 1e-6)
+    loss.backward()
+    rr = T(g["bce_r"]).requires_grad_(True)
+    from oracle import head
+    head.bce_with_eps(rr, T(g["bce_x"]), 1e-8).backward()
+    _report("bce grad", r.grad, rr.grad, 1e-6)
+    _report("bce saturated logits", binary_cross_entropy(T(g["bce_big_r"]).to(DEV), T(g["bce_big_x"]).to(DEV), 1e-8),
+            g["bce_big"], 1e-5)
+    f = f1_loss(T(g["f1_pred"]).to(DEV), T(g["f1_true"]).to(DEV), 1e-8)
+    _report("f1", torch.stack(list(f)), g["f1"], 1e-6)
+
+
+def test_adam_matches_torch():
+    from avvad.optim import FlatAdam
+    torch.manual_seed(1)
+    ps = [torch.randn(1000, 37), torch.randn(513)]
+    ref = [p.clone().requires_grad_(True) for p in ps]
+    mine = [torch.nn.Parameter(p.clone().to(DEV)) for p in ps]
+    opt_ref = torch.optim.Adam(ref, lr=1e-3, betas=(0.9, 0.999))
+    opt = FlatAdam(mine, lr=1e-3, betas=(0.9, 0.999))
+    for step in range(3):
+        gs = [torch.randn_like(p) for p in ps]
+        for p, gq in zip(ref, gs):
+            p.grad = gq.clone()
+        for p, gq in zip(mine, gs):
+            p.grad.copy_(gq.to(DEV))
+        opt_ref.step()
+        opt.step()
+        opt.zero_grad()
+    for i, (p, q) in enumerate(zip(mine, ref)):
+        _report("adam param %d after 3 steps" % i, p, q, 1e-6)
+
+
+# ------------------------------------------------------------------------------------------ trunk
+def _video_state():
+    from oracle import resnet18
+    spec = resnet18.trunk_keys("features.") + stategen.lstm_spec("lstm_video.", 512, 16, 2) + \
+        stategen.linear_spec("vad_video", 16, 1)
+    return stategen.make_state(spec, 7)
+
+
+def test_video_net_golden_eval_and_train():
+    from packages.models.Video_Net import DeepVAD_video
+    g = load_golden("video_h16")
+    x = T(g["x"]).to(DEV)
+    lens = g["lengths"].tolist()
+    m = DeepVAD_video(2, 16, 1)
+    m.load_state_dict(_video_state())
+    m = m.to(DEV).eval()
+    from avvad import nn as avnn
+    f = avnn.video_features(m.features, x, False)
+    _report("trunk features eval", f.reshape(-1, 512), g["feat_eval"], 1e-4)
+    _report("video net eval", m(x, lens), g["y_eval"], 1e-4)
+    _report("video net eval return_last", m(x, lens, return_last=True), g["y_last_eval"], 1e-4)
+    _report("video net single frame", m(x[:1, :1], [1]), g["y_single_eval"], 1e-4)
+    m.load_state_dict(_video_state())
+    m.train()
+    _report("video net train-mode BN", m(x, torch.LongTensor(lens)), g["y_train"], 1e-4)
+    sd = m.state_dict()
+    for k in [k for k in g if k.startswith("rs.")]:
+        _report("running stat " + k[3:], sd[k[3:]], g[k], 1e-5, 1e-5)
+    assert int(sd["features.1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("training", [True, False])
+def test_trunk_backward_vs_oracle(training):
+    """gradients of a random projection of the features w.r.t. every trunk parameter."""
+    from oracle import resnet18
+    from avvad import nn as avnn
+    from packages.models.Video_Net import DeepVAD_video
+    sd0 = _video_state()
+    N = 6
+    x = stategen.rand(21, N, 67, 67)
+    G = stategen.rand(22, N, 512)
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+          for k, v in sd0.items() if k.startswith("features.")}
+    ref = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), training)
+    (ref * G).sum().backward()
+    m = DeepVAD_video(2, 16, 1)
+    m.load_state_dict(sd0)
+    m = m.to(DEV).train(training)
+    f = avnn.trunk_forward(m.features, x.to(DEV), training)
+    _report("trunk fwd (training=%s)" % training, f, ref, 1e-4)
+    (f * G.to(DEV)).sum().backward()
+    worst = 0.0
+    for k, p in m.features.named_parameters():
+        r = sd["features." + k].grad
+        _report("trunk d/d%s" % k, p.grad, r, 2 * _grad_tol(r.numpy()))
+
+
+def test_av_net_golden_concat():
+    from packages.models.AV_Net import DeepVAD_AV
+    g = load_golden("av_concat_h16")
+    keys = [str(k) for k in g["keys"]]
+    shapes = [eval(str(s)) for s in g["shapes"]]
+    m = DeepVAD_AV(2, 16, 1)
+    m.load_state_dict(stategen.make_state(list(zip(keys, shapes)), 11))
+    m = m.to(DEV).eval()
+    a, v = T(g["audio"]).to(DEV), T(g["video"]).to(DEV)
+    lens = g["lengths"].tolist()
+    _report("AV net eval", m(a, v, lens), g["y_eval"], 1e-4)
+    m.train()
+    _report("AV net train", m(a, v, torch.LongTensor(lens).to(DEV)), g["y_train"], 1e-4)
+    with pytest.raises(Exception):
+        DeepVAD_AV(2, 16, 1, use_mcb=True).to(DEV)(a, v, lens)      # no silent fallback
+
+
+def test_av_wavenet_end_to_end_vs_oracle():
+    """The north-star model: WaveNet encoder + ResNet-18 tower + LSTM/FC head, loss and all gradients."""
+    from oracle import head, models
+    from packages.models.AV_Net import DeepVAD_AV
+    from packages.models.utils import batch_binary_cross_entropy
+    wcfg = dict(filter_width=2, quantization_channel=1, dilations=[1, 2, 4, 8, 16, 32], en_residual_channel=32,
+                en_dilation_channel=32, en_bottleneck_width=64, en_pool_kernel_size=4, use_bias=True)
+    torch.manual_seed(5)
+    m = DeepVAD_AV(2, 32, 1, wavenet_params=wcfg)
+    B, Tn = 3, 4
+    rf = 64
+    wave = torch.randn(B, 1, Tn * 256 + rf - 1) * 0.3
+    video = torch.randn(B, Tn, 67, 67)
+    tgt = (torch.rand(B, Tn, 1) > 0.5).float()
+    lens = [4, 2, 3]
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.detach().clone())
+          for k, v in m.state_dict().items()}
+    ref = models.av_net(sd, wave, video, lens, 2, training=True, wavenet_cfg=wcfg)
+    ref_loss = head.batch_loss(ref, tgt, lens, 1e-8)
+    ref_loss.backward()
+    m = m.to(DEV).train()
+    y = m(wave.to(DEV), video.to(DEV), torch.LongTensor(lens))
+    _report("AV+WaveNet logits (train)", y, ref, 1e-4)
+    loss = batch_binary_cross_entropy(y, tgt.to(DEV), lens, 1e-8)
+    _report("AV+WaveNet loss", loss, ref_loss, 1e-4)
+    loss.backward()
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            assert k.startswith("bn."), k          # the unused BatchNorm1d of the reference
+            continue
+        r = sd[k].grad
+        _report("AV+WaveNet d/d" + k, p.grad, r, 2 * _grad_tol(r.numpy()))
