@@ -51,6 +51,10 @@ class TrunkGrads(C.Structure):
     _fields_ = [("conv_w", FP * TRUNK_NCONV), ("bn_w", FP * TRUNK_NCONV), ("bn_b", FP * TRUNK_NCONV)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "Co", "KS", "stride", "pad")]
+
+
 class LstmDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("In", C.c_int), ("H", C.c_int), ("lengths", FP),
                 ("save_for_backward", C.c_int)]
@@ -65,6 +69,10 @@ SIGNATURES = {
     "avvad_wavenet_fwd": (C.c_int, [FP, C.POINTER(WavenetPtrs), FP, C.POINTER(WavenetDesc), FP, C.c_size_t, FP]),
     "avvad_wavenet_bwd": (C.c_int, [FP, C.POINTER(WavenetPtrs), FP, C.POINTER(WavenetPtrs), FP,
                                     C.POINTER(WavenetDesc), FP, C.c_size_t, FP]),
+    "avvad_conv2d_pack_weights": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
+    "avvad_conv2d_fwd": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
+    "avvad_conv2d_dgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), C.c_int, FP]),
+    "avvad_conv2d_wgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
     "avvad_trunk_workspace": (C.c_size_t, [C.POINTER(TrunkDesc)]),
     "avvad_trunk_fwd": (C.c_int, [FP, C.POINTER(TrunkParams), FP, C.POINTER(TrunkDesc), FP, C.c_size_t, FP]),
     "avvad_trunk_bwd": (C.c_int, [FP, C.POINTER(TrunkParams), FP, C.POINTER(TrunkGrads), C.POINTER(TrunkDesc), FP,

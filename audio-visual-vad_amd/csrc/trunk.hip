@@ -480,6 +480,43 @@ static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float
 }  // namespace
 
 // ====================================================================== C ABI
+// ---- single-convolution entry points (NHWC activations, packed weights): the building blocks of the trunk,
+// exported for unit tests and for bench.py's per-launch roofline timing.
+static bool conv_geom(const avvad_conv_desc* d, Geom* g) {
+  if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->Co <= 0 || d->KS <= 0 || d->stride <= 0 || d->pad < 0)
+    return false;
+  const int Ho = (d->H + 2 * d->pad - d->KS) / d->stride + 1, Wo = (d->W + 2 * d->pad - d->KS) / d->stride + 1;
+  if (Ho <= 0 || Wo <= 0 || (d->stride != 1 && d->stride != 2)) return false;
+  *g = Geom{d->N, d->H, d->W, d->C, Ho, Wo, d->Co, d->KS, d->stride, d->pad};
+  return true;
+}
+extern "C" int avvad_conv2d_pack_weights(const float* w_oihw, float* wf, float* wd, const avvad_conv_desc* d,
+                                         avvad_stream_t s) {
+  Geom g;
+  if (!w_oihw || !wf || !conv_geom(d, &g)) return AVVAD_EINVAL;
+  hipLaunchKernelGGL(pack_weights, dim3(ew_grid((long)g.Co * g.C * g.KS * g.KS)), dim3(256), 0, (hipStream_t)s, w_oihw, wf, wd,
+                     g.Co, g.C, g.KS);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+extern "C" int avvad_conv2d_fwd(const float* x, const float* wf, float* y, const avvad_conv_desc* d, avvad_stream_t s) {
+  Geom g;
+  if (!x || !wf || !y || !conv_geom(d, &g)) return AVVAD_EINVAL;
+  return conv_fwd(x, wf, y, g, (hipStream_t)s);
+}
+extern "C" int avvad_conv2d_dgrad(const float* dy, const float* wd, float* dx, const avvad_conv_desc* d, int accumulate,
+                                  avvad_stream_t s) {
+  Geom g;
+  if (!dy || !wd || !dx || !conv_geom(d, &g)) return AVVAD_EINVAL;
+  return conv_dgrad(dy, wd, dx, g, accumulate, (hipStream_t)s);
+}
+extern "C" int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_packed, const avvad_conv_desc* d,
+                                  avvad_stream_t s) {
+  Geom g;
+  if (!x || !dy || !dw_packed || !conv_geom(d, &g)) return AVVAD_EINVAL;
+  return conv_wgrad(x, dy, dw_packed, g, (hipStream_t)s);
+}
+
 extern "C" size_t avvad_trunk_workspace(const avvad_trunk_desc* d) {
   if (!d || d->N <= 0 || d->H < 32 || d->W < 32) return 0;
   Plan p;

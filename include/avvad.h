@@ -151,6 +151,23 @@ typedef struct {
   float* bn_b[AVVAD_TRUNK_NCONV];
 } avvad_trunk_grads;
 
+/* Single convolution on the implicit-GEMM engine (the trunk's building block; also what bench.py times
+ * per launch for the roofline).  x [N][H][W][C] NHWC, y [N][Ho][Wo][Co]; square kernel KS, stride 1|2.
+ * Weights are packed once from OIHW: wf [(kh,kw,c)][co] (forward) and wd [(kh,kw,co)][c] (dgrad; may be
+ * NULL).  C must be 1 (stem, forward/wgrad only) or a multiple of 32; Co a multiple of 4.
+ * wgrad writes the packed layout [(kh,kw,c)][co] (overwritten).  Replaces nn.Conv2d inside
+ * torchvision's resnet18 (packages/models/Video_Net.py:35-37). */
+typedef struct {
+  int N, H, W, C, Co, KS, stride, pad;
+} avvad_conv_desc;
+int avvad_conv2d_pack_weights(const float* w_oihw, float* wf, float* wd, const avvad_conv_desc* d,
+                              avvad_stream_t s);
+int avvad_conv2d_fwd(const float* x, const float* wf, float* y, const avvad_conv_desc* d, avvad_stream_t s);
+int avvad_conv2d_dgrad(const float* dy, const float* wd, float* dx, const avvad_conv_desc* d,
+                       int accumulate, avvad_stream_t s);
+int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_packed, const avvad_conv_desc* d,
+                       avvad_stream_t s);
+
 size_t avvad_trunk_workspace(const avvad_trunk_desc* d);
 int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* p, float* feat /* [N][512] */,
                     const avvad_trunk_desc* d, void* ws, size_t ws_bytes, avvad_stream_t s);
