@@ -13,6 +13,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
     if (hipGetLastError() != hipSuccess) return AVVAD_ELAUNCH; \
   } while (0)
 
+// hipGetLastError() is per host thread and also reports errors left behind by OTHER users of the runtime
+// in this process (e.g. a not-ready event query inside PyTorch): clear it on entry so that the check after
+// our launches only sees our launches.
+#define AVVAD_ENTER() (void)hipGetLastError()
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -54,5 +54,6 @@ int avvad_gemm_impl(const float* A, const float* B, const float* bias, float* C,
 
 extern "C" int avvad_gemm_f32(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d,
                               avvad_stream_t s) {
+  AVVAD_ENTER();
   return avvad_gemm_impl(A, B, bias, C, d, (hipStream_t)s);
 }

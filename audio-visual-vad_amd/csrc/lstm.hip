@@ -137,6 +137,7 @@ extern "C" size_t avvad_lstm_workspace(const avvad_lstm_desc* d) {
 extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const float* w_hh, const float* b_ih,
                                     const float* b_hh, float* y, const avvad_lstm_desc* d, void* wsv, size_t ws_bytes,
                                     avvad_stream_t sv) {
+  AVVAD_ENTER();
   if (!x || !w_ih || !w_hh || !b_ih || !b_hh || !y || !d || !wsv || !d->lengths || d->B <= 0 || d->T <= 0 || d->In <= 0 ||
       d->H <= 0)
     return AVVAD_EINVAL;
@@ -163,6 +164,7 @@ extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const flo
 extern "C" int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const float* w_hh, const float* y, const float* dy,
                                     float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
                                     const avvad_lstm_desc* d, void* wsv, size_t ws_bytes, avvad_stream_t sv) {
+  AVVAD_ENTER();
   if (!x || !w_ih || !w_hh || !y || !dy || !d || !wsv || !d->lengths) return AVVAD_EINVAL;
   hipStream_t s = (hipStream_t)sv;
   Ws w = carve(d, (float*)wsv);

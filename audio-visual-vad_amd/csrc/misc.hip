@@ -2,7 +2,8 @@
 #include "common.h"
 
 extern "C" const char* avvad_version(void) { return "avvad-hip 0.1 (gfx950, fp32 MFMA)"; }
-extern "C" int avvad_abi_version(void) { return 1; }
+extern "C" int avvad_abi_version(void) {
+  AVVAD_ENTER(); return 1; }
 
 namespace {
 
@@ -103,6 +104,7 @@ static inline int grid1(size_t n) { size_t b = (n + 255) / 256; return (int)(b >
 
 extern "C" int avvad_bce_masked(const float* logits, const float* targets, const int* lengths, float* loss, float* dlogits,
                                 int B, int T, int Y, float eps, avvad_stream_t s) {
+  AVVAD_ENTER();
   if (!logits || !targets || !lengths || !loss || B <= 0 || T <= 0 || Y <= 0) return AVVAD_EINVAL;
   hipLaunchKernelGGL(bce_masked_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, logits, targets, lengths, loss, dlogits, B, T,
                      Y, eps);
@@ -112,6 +114,7 @@ extern "C" int avvad_bce_masked(const float* logits, const float* targets, const
 
 extern "C" int avvad_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
                                float beta1, float beta2, float eps, int step, avvad_stream_t s) {
+  AVVAD_ENTER();
   if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) return AVVAD_EINVAL;
   if (n == 0) return AVVAD_OK;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
@@ -123,6 +126,7 @@ extern "C" int avvad_adam_step(float* param, const float* grad, float* exp_avg, 
 
 extern "C" int avvad_copy_cols(const float* src, float* dst, size_t rows, int ncols, int src_ld, int src_off, int dst_ld,
                                int dst_off, avvad_stream_t s) {
+  AVVAD_ENTER();
   if (!src || !dst || ncols <= 0 || src_off < 0 || dst_off < 0 || src_ld < src_off + ncols || dst_ld < dst_off + ncols)
     return AVVAD_EINVAL;
   if (rows == 0) return AVVAD_OK;
@@ -133,6 +137,7 @@ extern "C" int avvad_copy_cols(const float* src, float* dst, size_t rows, int nc
 }
 
 extern "C" int avvad_colsum_acc(const float* X, size_t rows, int cols, float* out, avvad_stream_t s) {
+  AVVAD_ENTER();
   if (!X || !out || cols <= 0) return AVVAD_EINVAL;
   if (rows == 0) return AVVAD_OK;
   hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 64)), dim3(256), 0, (hipStream_t)s, X, rows, cols, out);
@@ -141,6 +146,7 @@ extern "C" int avvad_colsum_acc(const float* X, size_t rows, int cols, float* ou
 }
 
 extern "C" int avvad_scale_by_device_scalar(float* x, const float* scalar, size_t n, avvad_stream_t s) {
+  AVVAD_ENTER();
   if (!x || !scalar) return AVVAD_EINVAL;
   if (n == 0) return AVVAD_OK;
   hipLaunchKernelGGL(scale_kernel, dim3(grid1(n)), dim3(256), 0, (hipStream_t)s, x, scalar, n);
@@ -149,6 +155,7 @@ extern "C" int avvad_scale_by_device_scalar(float* x, const float* scalar, size_
 }
 
 extern "C" int avvad_transpose_last2(const float* in, float* out, int B, int C, int T, avvad_stream_t s) {
+  AVVAD_ENTER();
   if (!in || !out || B <= 0 || C <= 0 || T <= 0) return AVVAD_EINVAL;
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(T, 32), cdiv(C, 32), B), dim3(256), 0, (hipStream_t)s, in, out, C, T);
   AVVAD_LAUNCH_CHECK();

@@ -492,6 +492,7 @@ static bool conv_geom(const avvad_conv_desc* d, Geom* g) {
 }
 extern "C" int avvad_conv2d_pack_weights(const float* w_oihw, float* wf, float* wd, const avvad_conv_desc* d,
                                          avvad_stream_t s) {
+  AVVAD_ENTER();
   Geom g;
   if (!w_oihw || !wf || !conv_geom(d, &g)) return AVVAD_EINVAL;
   hipLaunchKernelGGL(pack_weights, dim3(ew_grid((long)g.Co * g.C * g.KS * g.KS)), dim3(256), 0, (hipStream_t)s, w_oihw, wf, wd,
@@ -500,18 +501,21 @@ extern "C" int avvad_conv2d_pack_weights(const float* w_oihw, float* wf, float* 
   return AVVAD_OK;
 }
 extern "C" int avvad_conv2d_fwd(const float* x, const float* wf, float* y, const avvad_conv_desc* d, avvad_stream_t s) {
+  AVVAD_ENTER();
   Geom g;
   if (!x || !wf || !y || !conv_geom(d, &g)) return AVVAD_EINVAL;
   return conv_fwd(x, wf, y, g, (hipStream_t)s);
 }
 extern "C" int avvad_conv2d_dgrad(const float* dy, const float* wd, float* dx, const avvad_conv_desc* d, int accumulate,
                                   avvad_stream_t s) {
+  AVVAD_ENTER();
   Geom g;
   if (!dy || !wd || !dx || !conv_geom(d, &g)) return AVVAD_EINVAL;
   return conv_dgrad(dy, wd, dx, g, accumulate, (hipStream_t)s);
 }
 extern "C" int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_packed, const avvad_conv_desc* d,
                                   avvad_stream_t s) {
+  AVVAD_ENTER();
   Geom g;
   if (!x || !dy || !dw_packed || !conv_geom(d, &g)) return AVVAD_EINVAL;
   return conv_wgrad(x, dy, dw_packed, g, (hipStream_t)s);
@@ -526,6 +530,7 @@ extern "C" size_t avvad_trunk_workspace(const avvad_trunk_desc* d) {
 
 extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* prm, float* feat, const avvad_trunk_desc* d,
                                void* wsv, size_t ws_bytes, avvad_stream_t sv) {
+  AVVAD_ENTER();
   if (!frames || !prm || !feat || !d || !wsv || d->N <= 0 || d->H < 32 || d->W < 32) return AVVAD_EINVAL;
   hipStream_t s = (hipStream_t)sv;
   Plan p;
@@ -588,6 +593,7 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
 extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* prm, const float* dfeat,
                                const avvad_trunk_grads* g, const avvad_trunk_desc* d, void* wsv, size_t ws_bytes,
                                avvad_stream_t sv) {
+  AVVAD_ENTER();
   if (!frames || !prm || !dfeat || !g || !d || !wsv || !d->save_for_backward) return AVVAD_EINVAL;
   hipStream_t s = (hipStream_t)sv;
   Plan p;

@@ -272,6 +272,7 @@ extern "C" size_t avvad_wavenet_workspace(const avvad_wavenet_desc* d) {
 
 extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* prm, float* out, const avvad_wavenet_desc* d,
                                  void* wsv, size_t ws_bytes, avvad_stream_t sv) {
+  AVVAD_ENTER();
   Plan p;
   if (!wave || !prm || !out || !wsv || make_plan(d, &p)) return AVVAD_EINVAL;
   if (ws_bytes < p.total * sizeof(float)) return AVVAD_EWORKSPACE;
@@ -309,6 +310,7 @@ extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* 
 extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* prm, const float* dout,
                                  const avvad_wavenet_grads* g, float* dwave, const avvad_wavenet_desc* d, void* wsv,
                                  size_t ws_bytes, avvad_stream_t sv) {
+  AVVAD_ENTER();
   Plan p;
   if (!wave || !prm || !dout || !g || !wsv || make_plan(d, &p) || !d->save_for_backward) return AVVAD_EINVAL;
   if (ws_bytes < p.total * sizeof(float)) return AVVAD_EWORKSPACE;

@@ -104,7 +104,8 @@ def cpu_baseline(torch, n_seq=2):
     host: forward + loss + backward of the same AV model on n_seq x 16 frame-pairs, all host threads."""
     from oracle import head, models
     from packages.models.AV_Net import DeepVAD_AV
-    torch.set_num_threads(os.cpu_count())
+    # the GPU box gives one-GPU jobs a 16-CPU share of a much larger host: os.cpu_count() would oversubscribe
+    torch.set_num_threads(min(len(os.sched_getaffinity(0)), 16))
     torch.manual_seed(0)
     m = DeepVAD_AV(2, 1024, 1, wavenet_params=W0)
     sd = {k: (v.detach().clone().requires_grad_(v.dtype == torch.float32 and "running" not in k)) for k, v in m.state_dict().items()}
@@ -139,7 +140,7 @@ def parity_probe(torch):
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     ref = models.av_net(sd, wave, video, lens, 2, training=True, wavenet_cfg=cfg)
     y = m.to("cuda").train()(wave.cuda(), video.cuda(), lens)
-    return float((y.cpu() - ref).abs().max())
+    return float((y.detach().cpu() - ref).abs().max())
 
 
 def main():
@@ -179,8 +180,15 @@ def main():
         opt.zero_grad()
         return loss
 
+    def log(msg):
+        if rank == 0:
+            print("[bench %.1fs] %s" % (time.perf_counter() - t_start, msg), file=sys.stderr, flush=True)
+
+    t_start = time.perf_counter()
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    log("warm-up done")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -196,6 +204,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     final_loss = float(loss.item())
+    log("timed region: %.3f s for %d steps" % (dt, args.steps))
 
     if rank == 0:
         fp_per_step = world * N_SEQ * T_FRAMES
@@ -210,8 +219,11 @@ def main():
                           "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)}}
         if not args.no_extras:
             out["roofline"] = roofline_probe(torch, N_SEQ * T_FRAMES)
+            log("roofline probe done")
             out["cpu_ref_max_abs_delta"] = parity_probe(torch)
+            log("parity probe done")
             out["cpu_baseline"] = cpu_baseline(torch)
+            log("cpu baseline done")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
