@@ -7,6 +7,11 @@ on anything but the HIP kernels.
 import ctypes as C
 import os
 
+# PyTorch must be imported BEFORE the library is dlopen'ed: torch ships its own libamdhip64 and the kernels
+# have to run on THAT runtime instance (same device context, streams and allocations).  Loading
+# libavvad_hip.so first would pull a second HIP runtime into the process ("no ROCm-capable device").
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libavvad_hip.so")
 

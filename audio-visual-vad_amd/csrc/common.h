@@ -8,9 +8,14 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define AVVAD_LAUNCH_CHECK()                         \
-  do {                                               \
-    if (hipGetLastError() != hipSuccess) return AVVAD_ELAUNCH; \
+#include <stdio.h>
+#define AVVAD_LAUNCH_CHECK()                                                                      \
+  do {                                                                                            \
+    hipError_t e_ = hipGetLastError();                                                            \
+    if (e_ != hipSuccess) {                                                                       \
+      fprintf(stderr, "avvad: HIP error '%s' after launch at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+      return AVVAD_ELAUNCH;                                                                       \
+    }                                                                                             \
   } while (0)
 
 // hipGetLastError() is per host thread and also reports errors left behind by OTHER users of the runtime
