@@ -72,14 +72,15 @@ struct RowSegK {
   typedef NoCtx Ctx;
   const float* p;
   long ld, bstride;
-  int X, K, seglen, shift, relu;
+  int X, K, seglen, shift, relu, fw, dil;   // x = c*fw + tap (fw = 1: x = c); element += tap*dil
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
   __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
     float t = 0.f;
     if (x < X && k < K) {
       const int b = k / seglen, tt = k - b * seglen;
-      t = p[(long)b * bstride + (long)x * ld + tt + shift];
+      const int c = x / fw, tap = x - c * fw;
+      t = p[(long)b * bstride + (long)c * ld + tt + shift + tap * dil];
     }
     v[0] = relu ? fmaxf(t, 0.f) : t;
   }

@@ -23,7 +23,7 @@ namespace {
 
 constexpr int NCONV = AVVAD_TRUNK_NCONV;
 constexpr int MAXC = 512;
-constexpr int STAT_CHUNKS = 512;
+constexpr int STAT_CHUNKS = 256;
 
 // ------------------------------------------------------------------ static network description
 struct ConvSpec {
@@ -200,17 +200,33 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// sum the per-chunk partials of channel c = blockIdx.x*32 + (tid&31): 8 chunk-lanes per channel, fixed order
+// (deterministic); every thread of the 256-thread block must call it; lanes tid < 32 get the totals.
+__device__ __forceinline__ void chunk_sums(const double* __restrict__ part, int nchunk, int C, double& s, double& ss) {
+  __shared__ double sm[2][8][32];
+  const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0, b = 0;
+  if (c < C)
+    for (int i = kl; i < nchunk; i += 8) { a += part[((long)i * 2 + 0) * C + c]; b += part[((long)i * 2 + 1) * C + c]; }
+  sm[0][kl][cl] = a; sm[1][kl][cl] = b;
+  __syncthreads();
+  s = 0; ss = 0;
+  if (kl == 0)
+    for (int k = 0; k < 8; ++k) { s += sm[0][k][cl]; ss += sm[1][k][cl]; }
+}
+
 // finalize batch statistics -> scale/shift (+ saved mean/invstd, running-stat update)
 __global__ void bn_finalize(const double* __restrict__ part, int nchunk, long M, int C, const float* __restrict__ gamma,
                             const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv, int training,
                             float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
                             float* __restrict__ mean_o, float* __restrict__ invstd_o) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+  double s = 0, ss = 0;
+  if (training) chunk_sums(part, nchunk, C, s, ss);
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if (c >= C || threadIdx.x >= 32) return;
   float mean, var;
   if (training) {
-    double s = 0, ss = 0;
-    for (int i = 0; i < nchunk; ++i) { s += part[((long)i * 2 + 0) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
     const double m = s / (double)M;
     double v = ss / (double)M - m * m;
     if (v < 0) v = 0;
@@ -234,10 +250,10 @@ __global__ void bn_finalize(const double* __restrict__ part, int nchunk, long M,
 __global__ void bn_bwd_finalize(const double* __restrict__ part, int nchunk, long M, int C, const float* __restrict__ gamma,
                                 const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
                                 float* __restrict__ dbeta, float* __restrict__ coef) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
   double s = 0, ss = 0;
-  for (int i = 0; i < nchunk; ++i) { s += part[((long)i * 2 + 0) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
+  chunk_sums(part, nchunk, C, s, ss);
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if (c >= C || threadIdx.x >= 32) return;
   if (dbeta) dbeta[c] += (float)s;
   if (dgamma) dgamma[c] += (float)ss;
   coef[c] = gamma[c] * invstd[c];
@@ -451,7 +467,7 @@ static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, cons
     hipLaunchKernelGGL(col_reduce<0>, dim3(sc.nchunk), dim3(256), 0, s, craw, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, M, C, sc.rows_per_chunk, sc.part);
   }
-  hipLaunchKernelGGL(bn_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], prm->bn_b[i],
+  hipLaunchKernelGGL(bn_finalize, dim3(cdiv(C, 32)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], prm->bn_b[i],
                      prm->bn_rm[i], prm->bn_rv[i], d->training, d->momentum, d->eps, ws + p->bn_scale + i * MAXC,
                      ws + p->bn_shift + i * MAXC, ws + p->bn_mean + i * MAXC, ws + p->bn_invstd + i * MAXC);
   AVVAD_LAUNCH_CHECK();
@@ -468,7 +484,7 @@ static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float
   const float* invstd = ws + p->bn_invstd + i * MAXC;
   hipLaunchKernelGGL(col_reduce<1>, dim3(sc.nchunk), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, M, C,
                      sc.rows_per_chunk, sc.part);
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, 128)), dim3(128), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], invstd,
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, 32)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], invstd,
                      d->training, g->bn_w[i], g->bn_b[i], ws + p->coef);
   const long nq = M * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid(nq)), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, ws + p->coef, dx, gout,

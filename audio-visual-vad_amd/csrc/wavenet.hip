@@ -202,6 +202,219 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// ------------------------------------------------------------------ fused MFMA backward of a residual block (R = D = 32, fw = 2)
+// (A)  dz[d][t] = (z[d][t] > 0) * sum_r W_dense[r][d] * dS[r][t]            -- 16 MFMAs per 32-sample tile
+// Same lane geometry as the forward: column = time on the lane; the K index r = 2s+h is fed by lane half h.
+__global__ void __launch_bounds__(256)
+    wn_block_bwd_dz_mfma(const float* __restrict__ dS, const float* __restrict__ Z, const float* __restrict__ w_dense,
+                         float* __restrict__ DZ, int B, int Lo) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  float wt[16];  // A[i = d = li][k = r = 2s+lh] = W_dense[r][d]
+#pragma unroll
+  for (int s = 0; s < 16; ++s) wt[s] = w_dense[(2 * s + lh) * 32 + li];
+  for (long tile = wave0; tile < ntiles; tile += nwaves) {
+    const int b = (int)(tile / tiles_per_seq);
+    const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lo;
+    const long base = (long)b * 32 * Lo + t;
+    float g[16], z[16];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) g[s] = ok ? dS[base + (long)(2 * s + lh) * Lo] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = ok ? Z[base + (long)mfma32_row(r, lh) * Lo] : 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc = mfma32(wt[s], g[s], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok) DZ[base + (long)mfma32_row(r, lh) * Lo] = z[r] > 0.f ? acc[r] : 0.f;
+  }
+}
+
+// (B)  dS_in[c][t'] = (s_in[c][t'] > 0) * sum_{d,k} W_dil[d][c][k] * dz[d][t' - k*dil]  +  dS_out[c][t' - dil]
+//      (terms whose index falls outside [0, Lo) are zero)                        -- 32 MFMAs per tile
+__global__ void __launch_bounds__(256)
+    wn_block_bwd_dx_mfma(const float* __restrict__ DZ, const float* __restrict__ s_in, const float* __restrict__ dS_out,
+                         const float* __restrict__ w_dil, float* __restrict__ dS_in, int B, int Lin, int dil) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lin + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  float wt[32];  // A[i = c = li][k = (d = s, tap = lh)] = W_dil[d][c][tap]
+#pragma unroll
+  for (int s = 0; s < 32; ++s) wt[s] = w_dil[(s * 32 + li) * 2 + lh];
+  for (long tile = wave0; tile < ntiles; tile += nwaves) {
+    const int b = (int)(tile / tiles_per_seq);
+    const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;   // t' (input time)
+    const bool ok = t < Lin;
+    const int to = t - lh * dil;                                      // dz time of this lane half's tap
+    const bool okz = ok && to >= 0 && to < Lo;
+    const float* zp = DZ + (long)b * 32 * Lo + to;
+    float dz[32];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) dz[s] = okz ? zp[(long)s * Lo] : 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = mfma32(wt[s], dz[s], acc);
+    const bool okr = ok && t >= dil;                                  // residual: dS_out[c][t' - dil]
+    const float* sp = s_in + (long)b * 32 * Lin + t;
+    const float* rp = dS_out + (long)b * 32 * Lo + (t - dil);
+    float* op = dS_in + (long)b * 32 * Lin + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int c = mfma32_row(r, lh);
+      if (ok) {
+        float v = sp[(long)c * Lin] > 0.f ? acc[r] : 0.f;
+        if (okr) v += rp[(long)c * Lo];
+        op[(long)c * Lin] = v;
+      }
+    }
+  }
+}
+
+
+// ------------------------------------------------------------------ MFMA bottleneck + ReLU + adaptive average pool (R = 32, Bn % 32 == 0)
+// One wave per (sequence, pool bin, group of NT bn-tiles).  Transposed product z^T[t][bn] = s^T . Wb^T: the
+// activation tile is the A operand (lane = time, loaded as it lies in memory), the weights the B operand, so the
+// accumulator has TIME IN ITS REGISTERS and bn on the lane: the pool is 16 register adds + one lane-half swap.
+template <int NT>
+__global__ void __launch_bounds__(256)
+    tail_fwd_mfma(const float* __restrict__ s, const float* __restrict__ wb, const float* __restrict__ bb,
+                  float* __restrict__ out, int B, int Bn, int Lv, int P) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int ngrp = Bn / (32 * NT);
+  const long nitems = (long)B * P * ngrp;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long item = wave0; item < nitems; item += nwaves) {
+    const int grp = (int)(item % ngrp);
+    const int p = (int)((item / ngrp) % P);
+    const int b = (int)(item / ((long)ngrp * P));
+    const int bn0 = grp * 32 * NT;
+    int a, e;
+    pool_bin(p, Lv, P, a, e);
+    float w[NT][16], bias[NT], sum[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) w[n][k] = wb[(long)(bn0 + n * 32 + li) * 32 + 2 * k + lh];
+      bias[n] = bb ? bb[bn0 + n * 32 + li] : 0.f;
+      sum[n] = 0.f;
+    }
+    const float* sp = s + (long)b * 32 * Lv;
+    for (int t0 = a; t0 < e; t0 += 32) {
+      const int t = t0 + li;
+      const bool ok = t < e;
+      float x[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = ok ? sp[(long)(2 * k + lh) * Lv + t] : 0.f;
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc = mfma32(x[k], w[n][k], acc);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t0 + mfma32_row(r, lh) < e) sum[n] += fmaxf(acc[r] + bias[n], 0.f);
+      }
+    }
+    const float inv = 1.f / (float)(e - a);
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+      const float v = sum[n] + __shfl_xor(sum[n], 32, 64);
+      if (lh == 0) out[((long)b * Bn + bn0 + n * 32 + li) * P + p] = v * inv;
+    }
+  }
+}
+
+// backward of the tail for one 32-sample tile per wave: for every bn-tile recompute z (16 MFMAs), form
+// dz = (z>0) * pooled upstream gradient (written out for the weight gradients) and accumulate
+// dS[c][t] += sum_bn Wb[bn][c] dz[bn][t] (16 MFMAs, the z accumulator tile reused in place as the B operand).
+__global__ void __launch_bounds__(256)
+    tail_bwd_mfma(const float* __restrict__ s, const float* __restrict__ wb, const float* __restrict__ bb,
+                  const float* __restrict__ dout, float* __restrict__ dzt, float* __restrict__ dS, int B, int Bn, int Lv,
+                  int P) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_per_seq = (Lv + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long tile = wave0; tile < ntiles; tile += nwaves) {
+    const int b = (int)(tile / tiles_per_seq);
+    const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lv;
+    const float* sp = s + (long)b * 32 * Lv + t;
+    float x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = ok ? sp[(long)(2 * k + lh) * Lv] : 0.f;
+    // pool bins that contain t (at most two adjacent ones overlap)
+    int pb[3];
+    float pc[3];
+    {
+      const int c0 = ok ? (int)(((long)t * P) / Lv) : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int p = c0 - 1 + j;
+        int a = 0, e = 0;
+        const bool in = ok && p >= 0 && p < P;
+        if (in) pool_bin(p, Lv, P, a, e);
+        const bool hit = in && t >= a && t < e;
+        pb[j] = hit ? p : 0;
+        pc[j] = hit ? 1.f / (float)(e - a) : 0.f;
+      }
+    }
+    f32x16 accS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accS[r] = 0.f;
+    for (int nb = 0; nb < Bn; nb += 32) {
+      float wz[16], wt[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        wz[k] = wb[(long)(nb + li) * 32 + 2 * k + lh];            // A[i = bn][k = c] for z
+        wt[k] = wb[(long)(nb + mfma32_row(k, lh)) * 32 + li];      // A[i = c][k = bn] for dS
+      }
+      f32x16 accZ;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accZ[r] = bb ? bb[nb + mfma32_row(r, lh)] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) accZ = mfma32(wz[k], x[k], accZ);
+      float dz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long o = ((long)b * Bn + nb + mfma32_row(r, lh)) * P;
+        float g = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (pc[j] != 0.f) g += dout[o + pb[j]] * pc[j];
+        dz[r] = accZ[r] > 0.f ? g : 0.f;
+        if (ok) dzt[((long)b * Bn + nb + mfma32_row(r, lh)) * Lv + t] = dz[r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accS = mfma32(wt[r], dz[r], accS);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok) dS[((long)b * 32 + mfma32_row(r, lh)) * Lv + t] = accS[r];
+  }
+}
+
 // ------------------------------------------------------------------ plan / workspace
 struct Plan {
   int n;
@@ -244,17 +457,14 @@ static int wgrad_conv1d(const float* dy, const float* x, float* dw, int B, int C
   const long K = (long)B * Lout;
   if (K > 0x7fffffffL) return AVVAD_EINVAL;
   const int ktiles = cdiv(K, igemm::BK);
-  int split = 1024 / (cdiv(Cout, 64) * cdiv(Cin, 64));
+  int split = 1024 / (cdiv(Cout, 64) * cdiv(Cin * fw, 64));
   if (split > ktiles) split = ktiles;
   if (split < 1) split = 1;
-  for (int k = 0; k < fw; ++k) {
-    igemm::RowSegK a{dy, Lout, (long)Cout * Lout, Cout, (int)K, Lout, 0, 0};
-    igemm::RowSegK b{x, Lin, (long)Cin * Lin, Cin, (int)K, Lout, k * dil, relu_in};
-    igemm::EpiStore e{dw + k, (long)Cin * fw, nullptr, 2, fw};
-    int rc = igemm::launch<64, 64>(a, b, e, Cout, Cin, (int)K, split, s);
-    if (rc) return rc;
-  }
-  return AVVAD_OK;
+  // one launch for all taps: column n = ci*fw + k is exactly the [Cout][Cin][fw] weight layout
+  igemm::RowSegK a{dy, Lout, (long)Cout * Lout, Cout, (int)K, Lout, 0, 0, 1, 0};
+  igemm::RowSegK b{x, Lin, (long)Cin * Lin, Cin * fw, (int)K, Lout, 0, relu_in, fw, dil};
+  igemm::EpiStore e{dw, (long)Cin * fw, nullptr, 2};
+  return igemm::launch<64, 64>(a, b, e, Cout, Cin * fw, (int)K, split, s);
 }
 
 static void bias_grad(const float* dy, float* db, int B, int C, int L, hipStream_t s) {
@@ -301,8 +511,21 @@ extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* 
                          ws + p.s[i], ws + p.s[i + 1], B, D, R, p.L[i + 1], p.L[i + 1], 1, 1, 1, p.L[i] - p.L[i + 1], p.L[i]);
     }
   }
-  hipLaunchKernelGGL(tail_fwd_generic, dim3(d->P, B), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,
-                     d->use_bias ? prm->bott_b : (const float*)nullptr, out, R, d->Bn, p.L[p.n], d->P);
+  const float* bbp = d->use_bias ? prm->bott_b : (const float*)nullptr;
+  if (R == 32 && d->Bn % 32 == 0) {
+    const int nt = (d->Bn % 128 == 0) ? 4 : 1;
+    long blocks = ((long)B * d->P * (d->Bn / (32 * nt)) + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    if (nt == 4)
+      hipLaunchKernelGGL(tail_fwd_mfma<4>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w, bbp, out, B, d->Bn,
+                         p.L[p.n], d->P);
+    else
+      hipLaunchKernelGGL(tail_fwd_mfma<1>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w, bbp, out, B, d->Bn,
+                         p.L[p.n], d->P);
+  } else {
+    hipLaunchKernelGGL(tail_fwd_generic, dim3(d->P, B), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w, bbp, out, R, d->Bn,
+                       p.L[p.n], d->P);
+  }
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }
@@ -325,12 +548,21 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
   float* GB = ws + p.gb;  // d s_i
   // ---- tail: dz_t = relu'(z) * pooled-grad ; d s_N = Wb^T dz_t
   float* DZT = ws + p.dzt;
-  hipLaunchKernelGGL(tail_bwd_dz_generic, dim3(grid1((long)B * Bn * Lv)), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,
-                     d->use_bias ? prm->bott_b : (const float*)nullptr, dout, DZT, B, R, Bn, Lv, d->P);
+  const bool tail_mfma = (R == 32 && Bn % 32 == 0);
+  if (tail_mfma) {
+    long blocks = ((long)B * cdiv(Lv, 32) + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(tail_bwd_mfma, dim3((int)blocks), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,
+                       d->use_bias ? prm->bott_b : (const float*)nullptr, dout, DZT, GA, B, Bn, Lv, d->P);
+  } else {
+    hipLaunchKernelGGL(tail_bwd_dz_generic, dim3(grid1((long)B * Bn * Lv)), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,
+                       d->use_bias ? prm->bott_b : (const float*)nullptr, dout, DZT, B, R, Bn, Lv, d->P);
+  }
   if (g->bott_w && (rc = wgrad_conv1d(DZT, ws + p.s[p.n], g->bott_w, B, Bn, R, Lv, Lv, 1, 1, 0, s))) return rc;
   if (d->use_bias) bias_grad(DZT, g->bott_b, B, Bn, Lv, s);
-  hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Lv)), dim3(256), 0, s, DZT, prm->bott_w,
-                     (const float*)nullptr, (const float*)nullptr, GA, B, R, Bn, Lv, Lv, 1, 1, 0, 0);
+  if (!tail_mfma)
+    hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Lv)), dim3(256), 0, s, DZT, prm->bott_w,
+                       (const float*)nullptr, (const float*)nullptr, GA, B, R, Bn, Lv, Lv, 1, 1, 0, 0);
   // ---- residual blocks, last to first
   for (int i = p.n - 1; i >= 0; --i) {
     const int dil = d->dilations_h[i];
@@ -351,13 +583,25 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     // dense (1x1) layer: d W_dense = GA . relu(z)^T ; d b ; dz = (z>0) * W_dense^T GA
     if (g->dense_w_h[i] && (rc = wgrad_conv1d(GA, Z, g->dense_w_h[i], B, R, D, Lo, Lo, 1, 1, 1, s))) return rc;
     if (d->use_bias) bias_grad(GA, g->dense_b_h[i], B, R, Lo, s);
-    hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * D * Lo)), dim3(256), 0, s, GA, prm->dense_w_h[i], Z,
-                       (const float*)nullptr, DZ, B, D, R, Lo, Lo, 1, 1, 0, 0);
+    if (mfma_shape(d)) {
+      long blocks = ((long)B * cdiv(Lo, 32) + 3) / 4;
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Z, prm->dense_w_h[i], DZ, B, Lo);
+    } else {
+      hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * D * Lo)), dim3(256), 0, s, GA, prm->dense_w_h[i], Z,
+                         (const float*)nullptr, DZ, B, D, R, Lo, Lo, 1, 1, 0, 0);
+    }
     // dilated layer: d W_dil = dz . relu(s_i shifted)^T ; d b ; d s_i = (s_i>0) * W_dil^T (*) dz + left-padded GA
     if (g->dil_w_h[i] && (rc = wgrad_conv1d(DZ, si, g->dil_w_h[i], B, D, R, Lo, Li, fw, dil, 1, s))) return rc;
     if (d->use_bias) bias_grad(DZ, g->dil_b_h[i], B, D, Lo, s);
-    hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Li)), dim3(256), 0, s, DZ, prm->dil_w_h[i], si, GA,
-                       GB, B, R, D, Li, Lo, fw, dil, Li - Lo, Lo);
+    if (mfma_shape(d)) {
+      long blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
+      if (blocks > 1024) blocks = 1024;
+      hipLaunchKernelGGL(wn_block_bwd_dx_mfma, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
+    } else {
+      hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Li)), dim3(256), 0, s, DZ, prm->dil_w_h[i], si, GA,
+                         GB, B, R, D, Li, Lo, fw, dil, Li - Lo, Lo);
+    }
     float* t = GA; GA = GB; GB = t;
   }
   // ---- causal layer
