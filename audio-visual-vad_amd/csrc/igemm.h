@@ -27,7 +27,6 @@
 namespace igemm {
 
 constexpr int BK = 32;
-constexpr int NTHREADS = 256;
 
 struct NoCtx {};
 
@@ -122,20 +121,20 @@ struct ColPlain {
 };
 
 // ---------------------------------------------------------------- the kernel
-template <class Op, int BX>
+template <class Op, int BX, int NTH>
 struct Stage {
   static constexpr int VEC = Op::VEC;
-  static constexpr int NV = BX * BK / (NTHREADS * VEC);
+  static constexpr int NV = BX * BK / (NTH * VEC);
   static constexpr int LD = Op::KCONTIG ? BX + 1 : BX + 4;
   static constexpr int NCTX = Op::KCONTIG ? NV : 1;
   // thread -> (x_local, k_local) of its i-th vector
   __device__ static __forceinline__ void coord(int t, int i, int& xl, int& kl) {
     if (Op::KCONTIG) {
-      if (VEC == 4) { kl = (t & 7) * 4; xl = (t >> 3) + 32 * i; }
-      else { kl = t & 31; xl = (t >> 5) + 8 * i; }
+      if (VEC == 4) { kl = (t & 7) * 4; xl = (t >> 3) + (NTH / 8) * i; }
+      else { kl = t & 31; xl = (t >> 5) + (NTH / 32) * i; }
     } else {
-      if (VEC == 4) { constexpr int Q = BX / 4; xl = (t % Q) * 4; kl = t / Q + (NTHREADS / Q) * i; }
-      else { xl = t % BX; kl = t / BX + (NTHREADS / BX) * i; }
+      if (VEC == 4) { constexpr int Q = BX / 4; xl = (t % Q) * 4; kl = t / Q + (NTH / Q) * i; }
+      else { xl = t % BX; kl = t / BX + (NTH / BX) * i; }
     }
   }
   __device__ static __forceinline__ void to_lds(float* S, int t, const float (&st)[NV][VEC]) {
@@ -161,20 +160,23 @@ struct Stage {
 // whole tiles (plain data-parallel tiling, plain stores); otherwise they are equal shares, a tile may be split
 // between workers and split pieces are added with float atomics onto a pre-zeroed (or accumulating) output.
 // That removes the tile-quantisation loss of e.g. 648 or 288 tiles on 512 resident slots (37 % / 44 % idle).
-template <int BM, int BN, class AOp, class BOp, class Epi>
-__global__ void __launch_bounds__(NTHREADS)
+// NTH = 256: 4 waves as 2x2, each (BM/2)x(BN/2);  NTH = 512: 8 waves as 2x4, each (BM/2)x(BN/4) -- half the
+// accumulators and staging registers per wave, so twice the waves per SIMD fit next to the same LDS tile.
+template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi>
+__global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 128) ? 2 : 3))
     kernel(const AOp A, const BOp B, const Epi E, const int M, const int N, const int K, const int ktiles,
            const long iters, const int tile_aligned) {
-  typedef Stage<AOp, BM> SA;
-  typedef Stage<BOp, BN> SB;
-  constexpr int TM = BM / 64, TN = BN / 64;
+  typedef Stage<AOp, BM, NTH> SA;
+  typedef Stage<BOp, BN, NTH> SB;
+  constexpr int WGN = NTH / 128;                  // waves along N (2 or 4); 2 along M
+  constexpr int TM = BM / 64, TN = BN / (32 * WGN);
   constexpr int TILE = BK * SA::LD + BK * SB::LD;
-  __shared__ __attribute__((aligned(16))) float smem[2 * TILE];
+  __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * TILE];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WGN, wn = wave % WGN;
   const int ntn = (N + BN - 1) / BN;
 
   const long G = gridDim.x;
@@ -229,17 +231,17 @@ __global__ void __launch_bounds__(NTHREADS)
     __syncthreads();
 
     for (int kt = kt0; kt < kt1; ++kt) {
-      const int cur = (kt - kt0) & 1;
+      const int cur = DB ? ((kt - kt0) & 1) : 0;
       float* As = smem + cur * TILE;
       float* Bs = As + BK * SA::LD;
-      if (kt + 1 < kt1) {  // stage tile kt+1 into the other buffer (its readers passed the last barrier)
+      if (DB && kt + 1 < kt1) {  // stage tile kt+1 into the other buffer (its readers passed the last barrier)
         float* An = smem + (cur ^ 1) * TILE;
         SA::to_lds(An, t, sa);
         SB::to_lds(An + BK * SA::LD, t, sb);
         if (kt + 2 < kt1) gload(kt + 2);  // in flight during the MFMAs below
       }
       const float* ap = As + lh * SA::LD + wm * (BM / 2) + li;
-      const float* bp = Bs + lh * SB::LD + wn * (BN / 2) + li;
+      const float* bp = Bs + lh * SB::LD + wn * (BN / WGN) + li;
       float a[2][TM], b[2][TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
@@ -259,6 +261,12 @@ __global__ void __launch_bounds__(NTHREADS)
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[ks & 1][i], b[ks & 1][j], acc[i][j]);
       }
       __syncthreads();
+      if (!DB && kt + 1 < kt1) {  // single LDS buffer (more workgroups per CU): restage after everyone has read
+        SA::to_lds(smem, t, sa);
+        SB::to_lds(smem + BK * SA::LD, t, sb);
+        if (kt + 2 < kt1) gload(kt + 2);
+        __syncthreads();
+      }
     }
 
     const bool whole = (kt0 == 0 && kt1 == ktiles);
@@ -266,7 +274,7 @@ __global__ void __launch_bounds__(NTHREADS)
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / 2) + j * 32 + li;
+        const int n = n0 + wn * (BN / WGN) + j * 32 + li;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = m0 + wm * (BM / 2) + i * 32 + mfma32_row(r, lh);
@@ -287,7 +295,7 @@ static __global__ void zero_strided(float* C, int M, int N, long ldc, int cs) {
 
 constexpr int NUM_CU = 256;  // MI355X
 
-// split_k_hint <= 1: let the scheduler decide; > 1: the caller accumulates anyway (kept for API symmetry)
+// split_k_hint is kept for API symmetry; the scheduler decides the decomposition.
 template <int BM, int BN, class AOp, class BOp, class Epi>
 static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N, int K, int split_k_hint,
                          hipStream_t s) {
@@ -296,12 +304,18 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   const int ktiles = (K + BK - 1) / BK;
   const long ntiles = (long)cdiv(M, BM) * cdiv(N, BN);
   const long iters = ntiles * ktiles;
-  // resident workgroups per CU (LDS 2 x tile, VGPR budget of the instantiation)
-  const int per_cu = (BM == 128 && BN == 128) ? 2 : (BM * BN >= 128 * 64 ? 3 : 4);
+  const char* var = getenv("AVVAD_IGEMM_VARIANT");  // tuning aid: "db"/"sb" = 4-wave double/single LDS buffer, "w8" = 8 waves
+  constexpr bool BIG = (BM == 128 && BN == 128);
+  const int variant = var ? (var[0] == 'd' ? 0 : (var[0] == 's' ? 1 : 2)) : (BIG ? 2 : 1);
+  // resident workgroups per CU (LDS footprint / VGPR budget of the instantiation)
+  int per_cu;
+  if (variant == 0) per_cu = BIG ? 2 : (BM * BN >= 128 * 64 ? 3 : 4);
+  else if (variant == 1 || !BIG) per_cu = BIG ? 3 : (BM * BN >= 128 * 64 ? 4 : 6);
+  else per_cu = 2;
   long G = (long)NUM_CU * per_cu;
   const long rounds = (ntiles + G - 1) / G;
   const char* nsk = getenv("AVVAD_NO_STREAMK");   // debugging aid: "all", or the epilogue mode digit to restrict
-  const bool no_sk = nsk && (nsk[0] == 'a' || nsk[0] - '0' == e.mode);   // debugging aid: whole tiles only
+  const bool no_sk = nsk && (nsk[0] == 'a' || nsk[0] - '0' == e.mode);
   const bool aligned = no_sk || (ntiles >= G && (double)ntiles / (double)(rounds * G) >= 0.9);
   if (!aligned) {
     const long cap = iters / 4 > 0 ? iters / 4 : 1;  // >= 4 iterations per worker: prologue/epilogue amortised
@@ -312,8 +326,15 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
                          e.ldc, e.cs);
     }
   }
-  hipLaunchKernelGGL((kernel<BM, BN, AOp, BOp, Epi>), dim3((int)G), dim3(NTHREADS), 0, s, a, b, e, M, N, K, ktiles, iters,
-                     aligned ? 1 : 0);
+  if (variant == 0)
+    hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, iters,
+                       aligned ? 1 : 0);
+  else if (variant == 1 || !BIG)
+    hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, iters,
+                       aligned ? 1 : 0);
+  else
+    hipLaunchKernelGGL((kernel<BM, BN, true, (BIG ? 512 : 256), AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K,
+                       ktiles, iters, aligned ? 1 : 0);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

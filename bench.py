@@ -99,7 +99,7 @@ def roofline_probe(torch, n_frames, reps=5):
                           for (a, b, c_, d_, e, f, g) in per]}
 
 
-def cpu_baseline(torch, n_seq=2):
+def cpu_baseline(torch, n_seq=32):
     """The CPU oracle (a restatement of the reference's PyTorch-CPU arithmetic: kind "port") timed on this
     host: forward + loss + backward of the same AV model on n_seq x 16 frame-pairs, all host threads."""
     from oracle import head, models
@@ -112,7 +112,7 @@ def cpu_baseline(torch, n_seq=2):
     wave, video, target, lengths = make_inputs(torch, n_seq, 99, None)
     lens = lengths.tolist()
     times = []
-    for it in range(4):
+    for it in range(6):
         t0 = time.perf_counter()
         y = models.av_net(sd, wave, video, lens, 2, training=True, wavenet_cfg=W0)
         loss = head.batch_loss(y, target, lens, 1e-8)
@@ -124,7 +124,7 @@ def cpu_baseline(torch, n_seq=2):
     t = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": round(n_seq * T_FRAMES / t, 1), "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle AV model (WaveNet W0 + ResNet-18 + 2xLSTM1024 + FC), forward+loss+backward, %d seq x %d frames, "
-                      "median of 3 after 1 warm-up, %.2f s each" % (n_seq, T_FRAMES, t)}
+                      "median of 5 after 1 warm-up, %.2f s each" % (n_seq, T_FRAMES, t)}
 
 
 def parity_probe(torch):
