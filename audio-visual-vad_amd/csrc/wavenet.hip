@@ -415,12 +415,107 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// ------------------------------------------------------------------ fused MFMA weight/bias gradients of a residual block (R = D = 32, fw = 2)
+//   dW_dil[d][c][k] += sum_t dz[d][t] relu(s_in[c][t + k*dil])      db_dil[d]   += sum_t dz[d][t]
+//   dW_dense[r][d]  += sum_t dS[r][t] relu(z[d][t])                 db_dense[r] += sum_t dS[r][t]
+// The contraction index is TIME, so the MFMA wants channel-on-lane fragments (A[i = channel][k = t]).  Tiles are
+// loaded the coalesced way (lane = time), transposed through a per-wave 32x33 LDS tile (conflict-free both ways)
+// and fed to three 32x32 accumulators that live in registers across the wave's whole time range; one LDS +
+// global float-atomic reduction per workgroup at the end.  Replaces two split-K GEMM launches and two bias
+// reductions per layer.
+__global__ void __launch_bounds__(256)
+    wn_block_wgrad_mfma(const float* __restrict__ dS, const float* __restrict__ Z, const float* __restrict__ DZ,
+                        const float* __restrict__ s_in, float* __restrict__ dW_dil, float* __restrict__ db_dil,
+                        float* __restrict__ dW_dense, float* __restrict__ db_dense, int B, int Lin, int dil) {
+  __shared__ float tile[4][32 * 33];
+  __shared__ float red[3 * 1024 + 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  float* T = tile[wave];
+  for (int i = threadIdx.x; i < 3 * 1024 + 64; i += 256) red[i] = 0.f;
+
+  f32x16 acc0, acc1, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+  float bs_dz = 0.f, bs_ds = 0.f;
+
+  // fragment of X: f[s] = X[channel = li][t0 + 2s + lh]; X is read as X[c][t0 + li] (c = 2s' + lh), coalesced
+  auto transpose = [&](const float* base, long rstride, bool ok, bool relu, float (&f)[16]) {
+    float v[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      float x = ok ? base[(long)(2 * q + lh) * rstride] : 0.f;
+      v[q] = relu ? fmaxf(x, 0.f) : x;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) T[(2 * q + lh) * 33 + li] = v[q];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) f[q] = T[li * 33 + 2 * q + lh];
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  for (long tl = wave0; tl < ntiles; tl += nwaves) {
+    const int b = (int)(tl / tiles_per_seq);
+    const int t = (int)(tl - (long)b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lo;
+    const long oo = (long)b * 32 * Lo + t;
+    const long oi = (long)b * 32 * Lin + t;
+    float fdz[16], fx[16];
+    transpose(DZ + oo, Lo, ok, false, fdz);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bs_dz += fdz[q];
+    transpose(s_in + oi, Lin, ok, true, fx);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc0 = mfma32(fdz[q], fx[q], acc0);
+    transpose(s_in + oi + dil, Lin, ok, true, fx);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1 = mfma32(fdz[q], fx[q], acc1);
+    transpose(dS + oo, Lo, ok, false, fdz);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bs_ds += fdz[q];
+    transpose(Z + oo, Lo, ok, true, fx);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2 = mfma32(fdz[q], fx[q], acc2);
+  }
+
+  __syncthreads();  // red[] zeroed
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mfma32_row(r, lh);
+    atomicAdd(&red[row * 32 + li], acc0[r]);
+    atomicAdd(&red[1024 + row * 32 + li], acc1[r]);
+    atomicAdd(&red[2048 + row * 32 + li], acc2[r]);
+  }
+  atomicAdd(&red[3072 + li], bs_dz);
+  atomicAdd(&red[3104 + li], bs_ds);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 1024; i += 256) {
+    const int row = i >> 5, col = i & 31;
+    atomicAdd(dW_dil + (row * 32 + col) * 2 + 0, red[i]);
+    atomicAdd(dW_dil + (row * 32 + col) * 2 + 1, red[1024 + i]);
+    atomicAdd(dW_dense + i, red[2048 + i]);
+  }
+  if (threadIdx.x < 32) {
+    if (db_dil) atomicAdd(db_dil + threadIdx.x, red[3072 + threadIdx.x]);
+    if (db_dense) atomicAdd(db_dense + threadIdx.x, red[3104 + threadIdx.x]);
+  }
+}
+
 // ------------------------------------------------------------------ plan / workspace
 struct Plan {
   int n;
   int L[66];        // L[0] = causal output length, L[i+1] = after block i
   size_t s[66];     // offsets of s_i (floats); without save_for_backward only 2 ping-pong buffers
   size_t z, dz, ga, gb, dzt;
+  size_t zs[66];    // per-layer pre-ReLU dilation outputs kept for backward (MFMA shape); else 0
   size_t total;
 };
 static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
@@ -439,7 +534,9 @@ static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
     const size_t big = B * (size_t)(d->R > d->D ? d->R : d->D) * p->L[0];
     p->z = take(big); p->dz = take(big); p->ga = take(big); p->gb = take(big);
     p->dzt = take(B * d->Bn * p->L[p->n]);
+    for (int i = 0; i < p->n; ++i) p->zs[i] = (d->R == 32 && d->D == 32 && d->fw == 2) ? take(B * d->D * p->L[i + 1]) : 0;
   } else {
+    for (int i = 0; i < p->n; ++i) p->zs[i] = 0;
     const size_t a = take(B * d->R * p->L[0]), b2 = take(B * d->R * p->L[0]);
     for (int i = 0; i <= p->n; ++i) p->s[i] = (i & 1) ? b2 : a;
     p->z = take(B * d->D * p->L[0]);  // scratch of the generic (non-MFMA-shape) block path
@@ -501,8 +598,12 @@ extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* 
       const long ntiles = (long)B * cdiv(p.L[i + 1], 32);
       long blocks = (ntiles + 3) / 4;
       if (blocks > 1024) blocks = 1024;
-      hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
-                         prm->dense_w_h[i], be, ws + p.s[i + 1], (float*)nullptr, B, p.L[i], dil);
+      if (d->save_for_backward)   // keep z: one more write now, no recompute pass in backward
+        hipLaunchKernelGGL(wn_block_fwd_mfma<1>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
+                           prm->dense_w_h[i], be, ws + p.s[i + 1], ws + p.zs[i], B, p.L[i], dil);
+      else
+        hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
+                           prm->dense_w_h[i], be, ws + p.s[i + 1], (float*)nullptr, B, p.L[i], dil);
     } else {
       float* z = ws + p.z;
       hipLaunchKernelGGL(conv1d_fwd_generic, dim3(grid1((long)B * D * p.L[i + 1])), dim3(256), 0, s, ws + p.s[i],
@@ -569,36 +670,36 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     const int Li = p.L[i], Lo = p.L[i + 1];
     const float* si = ws + p.s[i];
     const float* bd = d->use_bias ? prm->dil_b_h[i] : nullptr;
-    // recompute z = dil_i(relu(s_i)) (pre-ReLU)
-    if (mfma_shape(d)) {
-      const long ntiles = (long)B * cdiv(Lo, 32);
-      long blocks = (ntiles + 3) / 4;
-      if (blocks > 1024) blocks = 1024;
-      hipLaunchKernelGGL(wn_block_fwd_mfma<2>, dim3((int)blocks), dim3(256), 0, s, si, prm->dil_w_h[i], bd,
-                         prm->dense_w_h[i], (const float*)nullptr, (float*)nullptr, Z, B, Li, dil);
-    } else {
+    const bool fast = mfma_shape(d);
+    float* Zi = fast ? ws + p.zs[i] : Z;
+    if (!fast)  // recompute z = dil_i(relu(s_i)) (pre-ReLU)
       hipLaunchKernelGGL(conv1d_fwd_generic, dim3(grid1((long)B * D * Lo)), dim3(256), 0, s, si, prm->dil_w_h[i], bd,
-                         (const float*)nullptr, Z, B, R, D, Li, Lo, fw, dil, 1, 0, 0);
-    }
-    // dense (1x1) layer: d W_dense = GA . relu(z)^T ; d b ; dz = (z>0) * W_dense^T GA
-    if (g->dense_w_h[i] && (rc = wgrad_conv1d(GA, Z, g->dense_w_h[i], B, R, D, Lo, Lo, 1, 1, 1, s))) return rc;
-    if (d->use_bias) bias_grad(GA, g->dense_b_h[i], B, R, Lo, s);
-    if (mfma_shape(d)) {
+                         (const float*)nullptr, Zi, B, R, D, Li, Lo, fw, dil, 1, 0, 0);
+    if (fast) {
+      // dz = (z>0) * W_dense^T dS ; then all four parameter gradients in one pass ; then d s_i
       long blocks = ((long)B * cdiv(Lo, 32) + 3) / 4;
       if (blocks > 1024) blocks = 1024;
-      hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Z, prm->dense_w_h[i], DZ, B, Lo);
-    } else {
-      hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * D * Lo)), dim3(256), 0, s, GA, prm->dense_w_h[i], Z,
-                         (const float*)nullptr, DZ, B, D, R, Lo, Lo, 1, 1, 0, 0);
-    }
-    // dilated layer: d W_dil = dz . relu(s_i shifted)^T ; d b ; d s_i = (s_i>0) * W_dil^T (*) dz + left-padded GA
-    if (g->dil_w_h[i] && (rc = wgrad_conv1d(DZ, si, g->dil_w_h[i], B, D, R, Lo, Li, fw, dil, 1, s))) return rc;
-    if (d->use_bias) bias_grad(DZ, g->dil_b_h[i], B, D, Lo, s);
-    if (mfma_shape(d)) {
-      long blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
+      hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], DZ, B, Lo);
+      if (g->dil_w_h[i] && g->dense_w_h[i]) {
+        long wb = ((long)B * cdiv(Lo, 32) + 31) / 32;   // >= 8 tiles per wave: the final reduction is amortised
+        if (wb > 512) wb = 512;
+        if (wb < 1) wb = 1;
+        hipLaunchKernelGGL(wn_block_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, DZ, si, g->dil_w_h[i],
+                           d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
+                           d->use_bias ? g->dense_b_h[i] : (float*)nullptr, B, Li, dil);
+      }
+      blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
       if (blocks > 1024) blocks = 1024;
       hipLaunchKernelGGL(wn_block_bwd_dx_mfma, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
     } else {
+      // dense (1x1) layer: d W_dense = GA . relu(z)^T ; d b ; dz = (z>0) * W_dense^T GA
+      if (g->dense_w_h[i] && (rc = wgrad_conv1d(GA, Zi, g->dense_w_h[i], B, R, D, Lo, Lo, 1, 1, 1, s))) return rc;
+      if (d->use_bias) bias_grad(GA, g->dense_b_h[i], B, R, Lo, s);
+      hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * D * Lo)), dim3(256), 0, s, GA, prm->dense_w_h[i], Zi,
+                         (const float*)nullptr, DZ, B, D, R, Lo, Lo, 1, 1, 0, 0);
+      // dilated layer: d W_dil = dz . relu(s_i shifted)^T ; d b ; d s_i = (s_i>0) * W_dil^T (*) dz + left-padded GA
+      if (g->dil_w_h[i] && (rc = wgrad_conv1d(DZ, si, g->dil_w_h[i], B, D, R, Lo, Li, fw, dil, 1, s))) return rc;
+      if (d->use_bias) bias_grad(DZ, g->dil_b_h[i], B, D, Lo, s);
       hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Li)), dim3(256), 0, s, DZ, prm->dil_w_h[i], si, GA,
                          GB, B, R, D, Li, Lo, fw, dil, Li - Lo, Lo);
     }

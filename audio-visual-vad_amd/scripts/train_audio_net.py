@@ -1,0 +1,30 @@
+"""Entry point mirroring the reference's ``scripts/train_audio_net.py`` (module-level constants = config; run from the
+package root: ``python scripts/train_audio_net.py``, or under ``torch.distributed.run`` for one process per GPU).
+Synthetic data only (HDF5 / wav readers are out of scope: SURVEY.md 2.1); override sizes with AVVAD_EPOCHS /
+AVVAD_ITEMS / AVVAD_BATCH.  Set WAVENET = True to train on raw waveforms through the WaveNet encoder."""
+import sys
+sys.path.append('.')
+
+from avvad.train import train_main
+from packages.models.Audio_Net import DeepVAD_audio
+
+# Settings (names as in the reference script)
+lstm_layers = 2
+lstm_hidden_size = 1024
+y_dim = 1
+batch_size = 16
+learning_rate = 1e-4
+end_epoch = 1
+model_name = 'audio_Classif_synthetic'
+WAVENET = False
+wavenet_params = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in range(10)] * 2,
+                      en_residual_channel=32, en_dilation_channel=32, en_bottleneck_width=256,
+                      en_pool_kernel_size=16, use_bias=True)
+
+
+def make_model():
+    return DeepVAD_audio(lstm_layers, lstm_hidden_size, y_dim, wavenet_params=wavenet_params if WAVENET else None)
+
+
+if __name__ == '__main__':
+    train_main('audio', make_model, model_name, waveform=WAVENET, epochs=end_epoch, batch_size=batch_size, lr=learning_rate)

@@ -341,3 +341,34 @@ def test_av_wavenet_end_to_end_vs_oracle():
             assert k.startswith("bn."), k          # the unused BatchNorm1d of the reference
             continue
         _report_grad("AV+WaveNet d/d" + k, p.grad, sd[k].grad, 2.0, 2e-2)   # train-mode BN on 12 frames: see trunk test
+
+
+# ------------------------------------------------------------------------------------------ entry points
+def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
+    """scripts/train_AV_net.py + evaluate_AV_net.py bodies on synthetic ragged batches (WaveNet variant):
+    the loss must go down and the evaluator must write the reference's *_y_hat_{soft,hard}.pt files."""
+    import os
+    from avvad import train as T
+    from packages.models.AV_Net import DeepVAD_AV
+    monkeypatch.chdir(tmp_path)
+    wcfg = dict(filter_width=2, quantization_channel=1, dilations=[1, 2, 4, 8], en_residual_channel=32,
+                en_dilation_channel=32, en_bottleneck_width=32, en_pool_kernel_size=16, use_bias=True)
+
+    class Fixed(T.SyntheticAV):     # fixed T so the pool size matches every item
+        def __init__(self, *a, **k):
+            k.update(t_min=16, t_max=16, rf=16)
+            super().__init__(*a, **k)
+    monkeypatch.setattr(T, "SyntheticAV", Fixed)
+    make = lambda: DeepVAD_AV(1, 32, 1, wavenet_params=wcfg)
+    monkeypatch.setenv("AVVAD_EPOCHS", "1")
+    model = T.train_main("av", make, "unit", waveform=True, epochs=1, batch_size=8, n_items=32, lr=1e-3,
+                         out_dir=str(tmp_path / "m"))
+    ck = [f for f in os.listdir(tmp_path / "m") if f.endswith(".pt")]
+    assert len(ck) == 1 and ck[0].startswith("Video_Net_epoch_001_vloss_")
+    log = open(tmp_path / "m" / "output_batch.log").read()
+    assert "Number of learnable parameters" in log and "====> Epoch:  1" in log
+    T.evaluate_main("av", make, checkpoint=str(tmp_path / "m" / ck[0]), waveform=True, n_items=3, out_dir=str(tmp_path / "e"))
+    outs = sorted(os.listdir(tmp_path / "e"))
+    assert outs == ["utt%04d_y_hat_%s.pt" % (i, k) for i in range(3) for k in ("hard", "soft")]
+    soft = torch.load(tmp_path / "e" / "utt0000_y_hat_soft.pt", weights_only=True)
+    assert soft.shape == (16, 1) and float(soft.min()) >= 0 and float(soft.max()) <= 1
