@@ -154,31 +154,58 @@ __global__ void __launch_bounds__(256)
   const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
 
-  // A operands, resident for the whole kernel
+  // A operands, resident for the whole kernel.  The per-lane fragment pattern is a 256-byte-strided gather, so
+  // the block first copies the 3072 weights coalesced into (padded, conflict-free) LDS and picks them from there.
+  __shared__ float wl[32 * 65 + 32 * 33 + 64];
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  for (int i = threadIdx.x; i < 1024; i += 256) wl[2080 + (i >> 5) * 33 + (i & 31)] = w_dense[i];
+  if (threadIdx.x < 32) {   // biases stay in LDS and seed the accumulators per tile (32 registers saved)
+    wl[3136 + threadIdx.x] = b_dil ? b_dil[threadIdx.x] : 0.f;
+    wl[3168 + threadIdx.x] = b_dense ? b_dense[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
   float wd[32];   // W_dil[d = li][c = s][tap = lh]
 #pragma unroll
-  for (int s = 0; s < 32; ++s) wd[s] = w_dil[(li * 32 + s) * 2 + lh];
+  for (int s = 0; s < 32; ++s) wd[s] = wl[li * 65 + s * 2 + lh];
   float we[16];   // W_dense[r = li][d = row(r', lh)]
-  float bz[16], bs[16];
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = mfma32_row(r, lh);
-    we[r] = w_dense[li * 32 + row];
-    bz[r] = b_dil ? b_dil[row] : 0.f;
-    bs[r] = b_dense ? b_dense[row] : 0.f;
-  }
+  for (int r = 0; r < 16; ++r) we[r] = wl[2080 + li * 33 + mfma32_row(r, lh)];
+  const float* bzl = wl + 3136;
+  const float* bsl = wl + 3168;
 
+  // Software pipeline across tiles: the NEXT tile's 48 loads are issued before the current tile's 48 MFMAs, so
+  // HBM latency hides under the matrix work inside one wave (the kernel is balanced HBM <-> MFMA).
+  // Loads are UNCONDITIONAL on a clamped (always valid) address and masked afterwards: a per-element
+  // "ok ? load : 0" makes hipcc branch around every load and wait for each one (32 serial round trips).
+  float xn[32], rn[16];
+  auto issue = [&](long tile) {
+    const long tl = tile < ntiles ? tile : ntiles - 1;
+    const int b = (int)(tl / tiles_per_seq);
+    const int t = (int)(tl - (long)b * tiles_per_seq) * 32 + li;
+    const int tcl = t < Lo ? t : 0;
+    const float* xp = s_in + (long)b * 32 * Lin + tcl + lh * dil;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) xn[c] = xp[(long)c * Lin];
+    if (MODE <= 1) {
+      const float* rp = s_in + (long)b * 32 * Lin + tcl + dil;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rn[r] = rp[(long)mfma32_row(r, lh) * Lin];
+    }
+  };
+  if (wave0 < ntiles) issue(wave0);
   for (long tile = wave0; tile < ntiles; tile += nwaves) {
     const int b = (int)(tile / tiles_per_seq);
     const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
     const bool ok = t < Lo;
-    const float* xp = s_in + (long)b * 32 * Lin + t + lh * dil;
-    float x[32];
+    float x[32], rv[16];
 #pragma unroll
-    for (int c = 0; c < 32; ++c) x[c] = ok ? xp[(long)c * Lin] : 0.f;
+    for (int c = 0; c < 32; ++c) x[c] = ok ? xn[c] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = (MODE <= 1 && ok) ? rn[r] : 0.f;
+    issue(tile + nwaves);     // in flight during the MFMAs below (clamped to the last tile when there is none)
     f32x16 acc;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = bz[r];
+    for (int r = 0; r < 16; ++r) acc[r] = bzl[mfma32_row(r, lh)];
 #pragma unroll
     for (int s = 0; s < 32; ++s) acc = mfma32(wd[s], fmaxf(x[s], 0.f), acc);
     if (MODE >= 1) {
@@ -188,10 +215,9 @@ __global__ void __launch_bounds__(256)
         if (ok) zp[(long)mfma32_row(r, lh) * Lo] = acc[r];
     }
     if (MODE <= 1) {
-      const float* rp = s_in + (long)b * 32 * Lin + t + dil;
       f32x16 acc2;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2[r] = bs[r] + (ok ? rp[(long)mfma32_row(r, lh) * Lin] : 0.f);
+      for (int r = 0; r < 16; ++r) acc2[r] = bsl[mfma32_row(r, lh)] + rv[r];
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2 = mfma32(we[r], fmaxf(acc[r], 0.f), acc2);
       float* op = s_out + (long)b * 32 * Lo + t;
@@ -215,19 +241,24 @@ __global__ void __launch_bounds__(256)
   const long ntiles = (long)B * tiles_per_seq;
   const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  __shared__ float wl[32 * 33];
+  for (int i = threadIdx.x; i < 1024; i += 256) wl[(i >> 5) * 33 + (i & 31)] = w_dense[i];
+  __syncthreads();
   float wt[16];  // A[i = d = li][k = r = 2s+lh] = W_dense[r][d]
 #pragma unroll
-  for (int s = 0; s < 16; ++s) wt[s] = w_dense[(2 * s + lh) * 32 + li];
+  for (int s = 0; s < 16; ++s) wt[s] = wl[(2 * s + lh) * 33 + li];
   for (long tile = wave0; tile < ntiles; tile += nwaves) {
     const int b = (int)(tile / tiles_per_seq);
     const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
     const bool ok = t < Lo;
-    const long base = (long)b * 32 * Lo + t;
+    const long base = (long)b * 32 * Lo + (ok ? t : 0);   // clamped: loads are unconditional, masked below
     float g[16], z[16];
 #pragma unroll
-    for (int s = 0; s < 16; ++s) g[s] = ok ? dS[base + (long)(2 * s + lh) * Lo] : 0.f;
+    for (int s = 0; s < 16; ++s) g[s] = dS[base + (long)(2 * s + lh) * Lo];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = ok ? Z[base + (long)mfma32_row(r, lh) * Lo] : 0.f;
+    for (int r = 0; r < 16; ++r) z[r] = Z[base + (long)mfma32_row(r, lh) * Lo];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) g[s] = ok ? g[s] : 0.f;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -251,40 +282,55 @@ __global__ void __launch_bounds__(256)
   const long ntiles = (long)B * tiles_per_seq;
   const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  __shared__ float wl[32 * 65];
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  __syncthreads();
   float wt[32];  // A[i = c = li][k = (d = s, tap = lh)] = W_dil[d][c][tap]
 #pragma unroll
-  for (int s = 0; s < 32; ++s) wt[s] = w_dil[(s * 32 + li) * 2 + lh];
+  for (int s = 0; s < 32; ++s) wt[s] = wl[s * 65 + li * 2 + lh];
+  // software pipeline across tiles (see wn_block_fwd_mfma): next tile's loads fly under this tile's MFMAs
+  float dzn[32], svn[16], rvn[16];
+  auto issue = [&](long tile) {
+    const long tl = tile < ntiles ? tile : ntiles - 1;
+    const int b = (int)(tl / tiles_per_seq);
+    const int t = (int)(tl - (long)b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lin;
+    const int to = t - lh * dil;
+    const bool okz = ok && to >= 0 && to < Lo;
+    const float* zp = DZ + (long)b * 32 * Lo + (okz ? to : 0);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) dzn[s] = zp[(long)s * Lo];
+    const bool okr = ok && t >= dil;
+    const float* sp = s_in + (long)b * 32 * Lin + (ok ? t : 0);
+    const float* rp = dS_out + (long)b * 32 * Lo + (okr ? t - dil : 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { svn[r] = sp[(long)mfma32_row(r, lh) * Lin]; rvn[r] = rp[(long)mfma32_row(r, lh) * Lo]; }
+  };
+  if (wave0 < ntiles) issue(wave0);
   for (long tile = wave0; tile < ntiles; tile += nwaves) {
     const int b = (int)(tile / tiles_per_seq);
     const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;   // t' (input time)
     const bool ok = t < Lin;
     const int to = t - lh * dil;                                      // dz time of this lane half's tap
     const bool okz = ok && to >= 0 && to < Lo;
-    const float* zp = DZ + (long)b * 32 * Lo + to;
-    float dz[32];
+    const bool okr = ok && t >= dil;                                  // residual: dS_out[c][t' - dil]
+    float dz[32], sv[16], rv[16];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) dz[s] = okz ? zp[(long)s * Lo] : 0.f;
+    for (int s = 0; s < 32; ++s) dz[s] = okz ? dzn[s] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] = svn[r]; rv[r] = okr ? rvn[r] : 0.f; }
+    issue(tile + nwaves);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int s = 0; s < 32; ++s) acc = mfma32(wt[s], dz[s], acc);
-    const bool okr = ok && t >= dil;                                  // residual: dS_out[c][t' - dil]
-    const float* sp = s_in + (long)b * 32 * Lin + t;
-    const float* rp = dS_out + (long)b * 32 * Lo + (t - dil);
     float* op = dS_in + (long)b * 32 * Lin + t;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int c = mfma32_row(r, lh);
-      if (ok) {
-        float v = sp[(long)c * Lin] > 0.f ? acc[r] : 0.f;
-        if (okr) v += rp[(long)c * Lo];
-        op[(long)c * Lin] = v;
-      }
-    }
+    for (int r = 0; r < 16; ++r)
+      if (ok) op[(long)mfma32_row(r, lh) * Lin] = (sv[r] > 0.f ? acc[r] : 0.f) + rv[r];
   }
 }
-
 
 // ------------------------------------------------------------------ MFMA bottleneck + ReLU + adaptive average pool (R = 32, Bn % 32 == 0)
 // One wave per (sequence, pool bin, group of NT bn-tiles).  Transposed product z^T[t][bn] = s^T . Wb^T: the
@@ -319,9 +365,12 @@ __global__ void __launch_bounds__(256)
     for (int t0 = a; t0 < e; t0 += 32) {
       const int t = t0 + li;
       const bool ok = t < e;
+      const int tcl = ok ? t : a;
       float x[16];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) x[k] = ok ? sp[(long)(2 * k + lh) * Lv + t] : 0.f;
+      for (int k = 0; k < 16; ++k) x[k] = sp[(long)(2 * k + lh) * Lv + tcl];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) x[k] = ok ? x[k] : 0.f;
 #pragma unroll
       for (int n = 0; n < NT; ++n) {
         f32x16 acc;
@@ -360,10 +409,12 @@ __global__ void __launch_bounds__(256)
     const int b = (int)(tile / tiles_per_seq);
     const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
     const bool ok = t < Lv;
-    const float* sp = s + (long)b * 32 * Lv + t;
+    const float* sp = s + (long)b * 32 * Lv + (ok ? t : 0);
     float x[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = ok ? sp[(long)(2 * k + lh) * Lv] : 0.f;
+    for (int k = 0; k < 16; ++k) x[k] = sp[(long)(2 * k + lh) * Lv];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = ok ? x[k] : 0.f;
     // pool bins that contain t (at most two adjacent ones overlap)
     int pb[3];
     float pc[3];
@@ -401,8 +452,7 @@ __global__ void __launch_bounds__(256)
         const long o = ((long)b * Bn + nb + mfma32_row(r, lh)) * P;
         float g = 0.f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
-          if (pc[j] != 0.f) g += dout[o + pb[j]] * pc[j];
+        for (int j = 0; j < 3; ++j) g = fmaf(dout[o + pb[j]], pc[j], g);   // pb is clamped to a valid bin, pc = 0 when not a member
         dz[r] = accZ[r] > 0.f ? g : 0.f;
         if (ok) dzt[((long)b * Bn + nb + mfma32_row(r, lh)) * Lv + t] = dz[r];
       }
@@ -445,17 +495,19 @@ __global__ void __launch_bounds__(256)
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
   float bs_dz = 0.f, bs_ds = 0.f;
 
-  // fragment of X: f[s] = X[channel = li][t0 + 2s + lh]; X is read as X[c][t0 + li] (c = 2s' + lh), coalesced
-  auto transpose = [&](const float* base, long rstride, bool ok, bool relu, float (&f)[16]) {
-    float v[16];
+  // fragment of X: f[s] = X[channel = li][t0 + 2s + lh]; X is read as X[c][t0 + li] (c = 2s' + lh), coalesced,
+  // unconditionally from a clamped address (masked afterwards: no per-load branches / waits)
+  auto gl = [&](const float* base, long rstride, float (&v)[16]) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      float x = ok ? base[(long)(2 * q + lh) * rstride] : 0.f;
-      v[q] = relu ? fmaxf(x, 0.f) : x;
-    }
+    for (int q = 0; q < 16; ++q) v[q] = base[(long)(2 * q + lh) * rstride];
+  };
+  auto xpose = [&](const float (&v)[16], bool ok, bool relu, float (&f)[16]) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) T[(2 * q + lh) * 33 + li] = v[q];
+    for (int q = 0; q < 16; ++q) {
+      const float x = ok ? v[q] : 0.f;
+      T[(2 * q + lh) * 33 + li] = relu ? fmaxf(x, 0.f) : x;
+    }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) f[q] = T[li * 33 + 2 * q + lh];
@@ -466,24 +518,30 @@ __global__ void __launch_bounds__(256)
     const int b = (int)(tl / tiles_per_seq);
     const int t = (int)(tl - (long)b * tiles_per_seq) * 32 + li;
     const bool ok = t < Lo;
-    const long oo = (long)b * 32 * Lo + t;
-    const long oi = (long)b * 32 * Lin + t;
-    float fdz[16], fx[16];
-    transpose(DZ + oo, Lo, ok, false, fdz);
+    const long oo = (long)b * 32 * Lo + (ok ? t : 0);
+    const long oi = (long)b * 32 * Lin + (ok ? t : 0);
+    float v0[16], v1[16], v2[16], v3[16], v4[16];   // all five operand tiles in flight at once
+    gl(DZ + oo, Lo, v0);
+    gl(s_in + oi, Lin, v1);
+    gl(s_in + oi + dil, Lin, v2);
+    gl(dS + oo, Lo, v3);
+    gl(Z + oo, Lo, v4);
+    float fa[16], fb[16];
+    xpose(v0, ok, false, fa);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bs_dz += fdz[q];
-    transpose(s_in + oi, Lin, ok, true, fx);
+    for (int q = 0; q < 16; ++q) bs_dz += fa[q];
+    xpose(v1, ok, true, fb);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc0 = mfma32(fdz[q], fx[q], acc0);
-    transpose(s_in + oi + dil, Lin, ok, true, fx);
+    for (int q = 0; q < 16; ++q) acc0 = mfma32(fa[q], fb[q], acc0);
+    xpose(v2, ok, true, fb);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc1 = mfma32(fdz[q], fx[q], acc1);
-    transpose(dS + oo, Lo, ok, false, fdz);
+    for (int q = 0; q < 16; ++q) acc1 = mfma32(fa[q], fb[q], acc1);
+    xpose(v3, ok, false, fa);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bs_ds += fdz[q];
-    transpose(Z + oo, Lo, ok, true, fx);
+    for (int q = 0; q < 16; ++q) bs_ds += fa[q];
+    xpose(v4, ok, true, fb);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc2 = mfma32(fdz[q], fx[q], acc2);
+    for (int q = 0; q < 16; ++q) acc2 = mfma32(fa[q], fb[q], acc2);
   }
 
   __syncthreads();  // red[] zeroed
@@ -597,7 +655,7 @@ extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* 
     if (mfma_shape(d)) {
       const long ntiles = (long)B * cdiv(p.L[i + 1], 32);
       long blocks = (ntiles + 3) / 4;
-      if (blocks > 1024) blocks = 1024;
+      if (blocks > 512) blocks = 512;    // 2 waves per SIMD resident; each wave walks >= 5 tiles at the bench shape
       if (d->save_for_backward)   // keep z: one more write now, no recompute pass in backward
         hipLaunchKernelGGL(wn_block_fwd_mfma<1>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
                            prm->dense_w_h[i], be, ws + p.s[i + 1], ws + p.zs[i], B, p.L[i], dil);
@@ -678,18 +736,18 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     if (fast) {
       // dz = (z>0) * W_dense^T dS ; then all four parameter gradients in one pass ; then d s_i
       long blocks = ((long)B * cdiv(Lo, 32) + 3) / 4;
-      if (blocks > 1024) blocks = 1024;
+      if (blocks > 768) blocks = 768;
       hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], DZ, B, Lo);
       if (g->dil_w_h[i] && g->dense_w_h[i]) {
-        long wb = ((long)B * cdiv(Lo, 32) + 31) / 32;   // >= 8 tiles per wave: the final reduction is amortised
-        if (wb > 512) wb = 512;
+        long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave: the final reduction is amortised
+        if (wb > 768) wb = 768;
         if (wb < 1) wb = 1;
         hipLaunchKernelGGL(wn_block_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, DZ, si, g->dil_w_h[i],
                            d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
                            d->use_bias ? g->dense_b_h[i] : (float*)nullptr, B, Li, dil);
       }
       blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
-      if (blocks > 1024) blocks = 1024;
+      if (blocks > 512) blocks = 512;
       hipLaunchKernelGGL(wn_block_bwd_dx_mfma, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
     } else {
       // dense (1x1) layer: d W_dense = GA . relu(z)^T ; d b ; dz = (z>0) * W_dense^T GA
