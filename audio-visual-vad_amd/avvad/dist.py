@@ -80,8 +80,15 @@ class BucketReducer:
         if self.world > 1:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+            try:                      # gradients written in place by the HIP backward bypass autograd's hooks
+                from . import ops
+                ops.GRAD_SINKS.append(self._on_grad)
+            except ImportError:       # CPU-only use of the reducer (gloo tests)
+                pass
 
     def _on_grad(self, p):
+        if id(p) not in self.param_bucket:
+            return
         b = self.param_bucket[id(p)]
         self.pending[b] += 1
         if self.pending[b] == self.buckets[b][2]:

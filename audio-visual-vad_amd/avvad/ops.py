@@ -30,6 +30,39 @@ def _ws(nbytes, device):
     return torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
 
 
+# ---------------------------------------------------------------------------
+# Direct gradient accumulation.  Every backward kernel ACCUMULATES (+=) into the gradient pointer it is
+# given, so when a parameter already owns a gradient buffer (FlatAdam re-homes all of them into one flat
+# buffer) the kernel writes there directly and the Function returns None for that input: no zero-fill, no
+# temporary, no autograd add kernel per parameter (~300 tiny launches per step saved).  Because autograd's
+# AccumulateGrad node is bypassed, its post-accumulate hooks do not fire: listeners (the DP bucket reducer)
+# register in GRAD_SINKS and are told about every parameter written this way.
+GRAD_SINKS = []
+
+
+def _grad_target(p, needed):
+    """-> (tensor to accumulate into or None, direct?)"""
+    if not needed or p is None:
+        return None, False
+    g = getattr(p, "grad", None)
+    if isinstance(p, torch.nn.Parameter) and g is not None and g.is_contiguous() and g.dtype == torch.float32:
+        return g, True
+    return torch.zeros_like(p), False
+
+
+def _finish_grads(params, targets):
+    """returned gradients for autograd (None where written in place) + sink notification"""
+    out = []
+    for p, (g, direct) in zip(params, targets):
+        if direct:
+            for sink in GRAD_SINKS:
+                sink(p)
+            out.append(None)
+        else:
+            out.append(g)
+    return out
+
+
 def lengths_i32(lengths, device):
     """`lengths` arrives as a LongTensor (train loop) or a Python list (eval)."""
     if isinstance(lengths, torch.Tensor):
@@ -56,6 +89,7 @@ class LinearFn(torch.autograd.Function):
         gemm(x2, w, y, rows, N, K, K, K, N, transB=True, bias=_dev(bias, "bias") if bias is not None else None)
         ctx.save_for_backward(x2, w)
         ctx.has_bias = bias is not None
+        ctx.prm = (weight, bias)
         return y.view(x.shape[:-1] + (N,))
 
     @staticmethod
@@ -69,12 +103,13 @@ class LinearFn(torch.autograd.Function):
             dx = torch.empty_like(x2)
             gemm(dy2, w, dx, rows, K, N, N, K, K)                       # [rows,N] x [N,K]
             dx = dx.view(dy.shape[:-1] + (K,))
-        if ctx.needs_input_grad[1]:
-            dw = torch.zeros_like(w)
-            gemm(dy2, x2, dw, N, K, rows, N, K, K, transA=True, accumulate=True)   # dy^T x
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(N, dtype=torch.float32, device=dy.device)
-            L.check(L.lib().avvad_colsum_acc(L.ptr(dy2), rows, N, L.ptr(db), _stream()), "avvad_colsum_acc")
+        tw = _grad_target(ctx.prm[0], ctx.needs_input_grad[1])
+        tb = _grad_target(ctx.prm[1], ctx.has_bias and ctx.needs_input_grad[2])
+        if tw[0] is not None:
+            gemm(dy2, x2, tw[0], N, K, rows, N, K, K, transA=True, accumulate=True)   # dy^T x
+        if tb[0] is not None:
+            L.check(L.lib().avvad_colsum_acc(L.ptr(dy2), rows, N, L.ptr(tb[0]), _stream()), "avvad_colsum_acc")
+        dw, db = _finish_grads(ctx.prm, (tw, tb))
         return dx, dw, db
 
 
@@ -94,6 +129,7 @@ class LstmLayerFn(torch.autograd.Function):
         L.check(L.lib().avvad_lstm_layer_fwd(L.ptr(x), L.ptr(w_ih), L.ptr(w_hh), L.ptr(b_ih), L.ptr(b_hh), L.ptr(y),
                                              C.byref(d), L.ptr(ws), ws.numel() * 4, _stream()), "avvad_lstm_layer_fwd")
         ctx.save_for_backward(x, lens32, w_ih, w_hh, y, ws)
+        ctx.prm = (w_ih, w_hh, b_ih, b_hh)
         return y
 
     @staticmethod
@@ -104,14 +140,11 @@ class LstmLayerFn(torch.autograd.Function):
         dy = _dev(dy, "dy")
         d = L.LstmDesc(B, T, In, H, lens32.data_ptr(), 1)
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
-        need_w = any(ctx.needs_input_grad[2:])
-        dw_ih = torch.zeros_like(w_ih) if need_w else None
-        dw_hh = torch.zeros_like(w_hh) if need_w else None
-        db_ih = torch.zeros(4 * H, dtype=torch.float32, device=x.device) if need_w else None
-        db_hh = torch.zeros(4 * H, dtype=torch.float32, device=x.device) if need_w else None
+        tg = [_grad_target(p, ctx.needs_input_grad[2 + i]) for i, p in enumerate(ctx.prm)]
         L.check(L.lib().avvad_lstm_layer_bwd(L.ptr(x), L.ptr(w_ih), L.ptr(w_hh), L.ptr(y), L.ptr(dy), L.ptr(dx),
-                                             L.ptr(dw_ih), L.ptr(dw_hh), L.ptr(db_ih), L.ptr(db_hh), C.byref(d),
+                                             L.ptr(tg[0][0]), L.ptr(tg[1][0]), L.ptr(tg[2][0]), L.ptr(tg[3][0]), C.byref(d),
                                              L.ptr(ws), ws.numel() * 4, _stream()), "avvad_lstm_layer_bwd")
+        dw_ih, dw_hh, db_ih, db_hh = _finish_grads(ctx.prm, tg)
         return dx, None, dw_ih, dw_hh, db_ih, db_hh
 
 
@@ -153,6 +186,7 @@ class WavenetFn(torch.autograd.Function):
         n = len(cfg["dilations"])
         if qc != cfg["quantization_channel"] or len(params) != 4 + 4 * n:
             raise L.AvvadError("wavenet: bad input channels / parameter list")
+        ctx.owners = params          # the Parameter objects themselves (their .grad may be written directly)
         params = tuple(None if t is None else _dev(t, "param") for t in params)
         dil_arr = (C.c_int * max(1, n))(*cfg["dilations"])
         save = any(ctx.needs_input_grad)
@@ -178,12 +212,16 @@ class WavenetFn(torch.autograd.Function):
         B, qc, Lin = wave.shape
         dil_arr = (C.c_int * max(1, n))(*cfg["dilations"])
         d = WavenetFn._desc(cfg, B, Lin, dil_arr, True)
-        grads = tuple(None if t is None else torch.zeros_like(t) for t in params)
+        owners = ctx.owners
+        tg = [_grad_target(o if o is not None else t, t is not None and ctx.needs_input_grad[2 + i])
+              for i, (o, t) in enumerate(zip(owners, params))]
+        grads = tuple(g for g, _ in tg)
         dwave = torch.empty_like(wave) if ctx.needs_input_grad[0] else None
         p, keep1 = WavenetFn._ptrs(params, n)
         g, keep2 = WavenetFn._ptrs(grads, n)
         L.check(L.lib().avvad_wavenet_bwd(L.ptr(wave), C.byref(p), L.ptr(_dev(dout, "dout")), C.byref(g), L.ptr(dwave),
                                           C.byref(d), L.ptr(ws), ws.numel() * 4, _stream()), "avvad_wavenet_bwd")
+        grads = tuple(_finish_grads([o if o is not None else t for o, t in zip(owners, params)], tg))
         return (dwave, None) + grads
 
 
@@ -211,6 +249,7 @@ class TrunkFn(torch.autograd.Function):
         n = L.TRUNK_NCONV
         if len(ts) != 5 * n:
             raise L.AvvadError("trunk: expected %d tensors" % (5 * n))
+        owners = ts
         ts = tuple(_dev(t, "trunk tensor") for t in ts)
         save = any(ctx.needs_input_grad[4:4 + 3 * n])
         d = L.TrunkDesc(N, H, W, int(training), float(momentum), float(eps), int(save))
@@ -222,6 +261,7 @@ class TrunkFn(torch.autograd.Function):
         if save:
             ctx.save_for_backward(frames, ws, *ts)
             ctx.cfg = (int(training), float(momentum), float(eps))
+            ctx.owners = owners
         return feat
 
     @staticmethod
@@ -234,16 +274,13 @@ class TrunkFn(torch.autograd.Function):
         d = L.TrunkDesc(N, H, W, training, momentum, eps, 1)
         p = TrunkFn._params(ts)
         g = L.TrunkGrads()
-        grads = []
-        for i in range(3 * n):
-            if ctx.needs_input_grad[4 + i]:
-                gt = torch.zeros_like(ts[i])
-                grads.append(gt)
+        tg = [_grad_target(ctx.owners[i], ctx.needs_input_grad[4 + i]) for i in range(3 * n)]
+        for i, (gt, _) in enumerate(tg):
+            if gt is not None:
                 (g.conv_w, g.bn_w, g.bn_b)[i // n][i % n] = gt.data_ptr()
-            else:
-                grads.append(None)
         L.check(L.lib().avvad_trunk_bwd(L.ptr(frames), C.byref(p), L.ptr(_dev(dfeat, "dfeat")), C.byref(g), C.byref(d),
                                         L.ptr(ws), ws.numel() * 4, _stream()), "avvad_trunk_bwd")
+        grads = _finish_grads(ctx.owners[:3 * n], tg)
         return (None, None, None, None) + tuple(grads) + (None,) * (2 * n)
 
 

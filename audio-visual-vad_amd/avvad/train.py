@@ -91,7 +91,7 @@ def run_epoch(model, kind, loader, device, waveform, opt=None, reducer=None, log
         tot["n"] += 1
         if log and i % log_interval == 0:
             log("%s batch %4d  loss %.3f  acc %.3f  prec %.3f  rec %.3f  f1 %.3f"
-                % ("train" if train else "valid", i, float(loss), float(acc), float(prec), float(rec), float(f1)))
+                % ("train" if train else "valid", i, float(loss.detach()), float(acc), float(prec), float(rec), float(f1)))
     n = max(tot.pop("n"), 1)
     return {k: v / n for k, v in tot.items()}
 

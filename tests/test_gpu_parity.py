@@ -372,3 +372,46 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     assert outs == ["utt%04d_y_hat_%s.pt" % (i, k) for i in range(3) for k in ("hard", "soft")]
     soft = torch.load(tmp_path / "e" / "utt0000_y_hat_soft.pt", weights_only=True)
     assert soft.shape == (16, 1) and float(soft.min()) >= 0 and float(soft.max()) <= 1
+
+
+def test_training_steps_match_cpu_adam():
+    """3 optimisation steps (FlatAdam over the flat buffer, gradients accumulated in place by the HIP backward)
+    against the oracle model trained with torch.optim.Adam on the CPU: same loss trajectory."""
+    from avvad.optim import FlatAdam
+    from oracle import head, models
+    from packages.models.AV_Net import DeepVAD_AV
+    from packages.models.utils import batch_binary_cross_entropy
+    wcfg = dict(filter_width=2, quantization_channel=1, dilations=[1, 2, 4, 8], en_residual_channel=32,
+                en_dilation_channel=32, en_bottleneck_width=32, en_pool_kernel_size=4, use_bias=True)
+    torch.manual_seed(11)
+    m = DeepVAD_AV(1, 32, 1, wavenet_params=wcfg)
+    B, Tn = 4, 4
+    wave = torch.randn(B, 1, Tn * 256 + 15) * 0.3
+    video = torch.randn(B, Tn, 67, 67)
+    tgt = (torch.rand(B, Tn, 1) > 0.5).float()
+    lens = [4, 3, 4, 2]
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.detach().clone())
+          for k, v in m.state_dict().items()}
+    cpu_params = [v for k, v in sd.items() if v.requires_grad and not k.startswith("bn.")]
+    opt_ref = torch.optim.Adam(cpu_params, lr=1e-3, betas=(0.9, 0.999))
+    m = m.to(DEV).train()
+    opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+    ref_losses, losses = [], []
+    for step in range(3):
+        y = models.av_net(sd, wave, video, lens, 1, training=True, wavenet_cfg=wcfg)
+        l = head.batch_loss(y, tgt, lens, 1e-8)
+        opt_ref.zero_grad()
+        l.backward()
+        opt_ref.step()
+        ref_losses.append(float(l))
+        yg = m(wave.to(DEV), video.to(DEV), torch.LongTensor(lens))
+        lg = batch_binary_cross_entropy(yg, tgt.to(DEV), lens, 1e-8)
+        lg.backward()
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(lg))
+    _report("loss trajectory over 3 Adam steps", np.array(losses), np.array(ref_losses), 2e-3)
+    assert losses[2] < losses[0]
+    # the in-place path really was used: .grad tensors are views of the flat buffer
+    p0 = next(m.parameters())
+    assert p0.grad.data_ptr() >= opt.flat_grad.data_ptr() and p0.grad.data_ptr() < opt.flat_grad.data_ptr() + 4 * opt.flat_grad.numel()
