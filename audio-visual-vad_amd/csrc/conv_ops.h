@@ -86,6 +86,85 @@ struct Im2colDgrad {
   }
 };
 
+
+// ---- stride-2 dgrad, one input-pixel parity class (ph, pw) at a time.
+// For stride 2 only the taps with kh = (hi + pad) mod 2 (step 2) reach an input row hi, so the 3x3 kernel splits
+// into 4 classes with 1, 2, 2 and 4 live taps (the 1x1 downsample: 1 class with 1 tap) -- 2.25/9 of the MACs of
+// the dense formulation, which multiplies structural zeros.  Rows of this GEMM enumerate the class's pixels
+// (hi = 2i + ph, wi = 2j + pw); K enumerates (live tap, co).
+struct S2Class {
+  int ph, pw, Hc, Wc;   // class grid
+  int kh0, kw0, nkh, nkw;
+  int oh, ow;           // ho = i + oh - a, wo = j + ow - b for tap (kh0 + 2a, kw0 + 2b)
+};
+struct Im2colDgradS2 {
+  static constexpr bool KCONTIG = true;
+  static constexpr int VEC = 4;
+  struct Ctx { int base, i, j; };
+  const float* dy;
+  Geom g;
+  S2Class c;
+  int M;
+  __device__ __forceinline__ Ctx prep(int m) const {
+    Ctx x;
+    if (m >= M) { x.base = -1; x.i = x.j = 0; return x; }
+    const int hw = c.Hc * c.Wc;
+    const int n = m / hw, r = m - n * hw;
+    x.i = r / c.Wc;
+    x.j = r - x.i * c.Wc;
+    x.base = n * g.Ho * g.Wo;
+    return x;
+  }
+  __device__ __forceinline__ void load(const Ctx& x, int, int k0, int kin, float* v) const {
+    const int seg = k0 / g.Co;
+    const int c0 = k0 - seg * g.Co + kin;
+    const int a = seg / c.nkw, b = seg - a * c.nkw;
+    const int ho = x.i + c.oh - a, wo = x.j + c.ow - b;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (x.base >= 0 && (unsigned)ho < (unsigned)g.Ho && (unsigned)wo < (unsigned)g.Wo) {
+      const float4 t = *reinterpret_cast<const float4*>(dy + ((long)(x.base + ho * g.Wo + wo) * g.Co + c0));
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  }
+};
+// weight rows of the live taps: element (k, x) = p[(rowbase[k / seglen] + k % seglen) * ld + x]
+struct ColSegRows {
+  static constexpr bool KCONTIG = false;
+  static constexpr int VEC = 4;
+  typedef igemm::NoCtx Ctx;
+  const float* p;
+  long ld;
+  int X, K, seglen;
+  int rowbase[4];
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
+  __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
+    const int k = k0 + kin;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (k < K && x < X) {
+      const int seg = k / seglen;
+      const float4 t = *reinterpret_cast<const float4*>(p + (long)(rowbase[seg] + k - seg * seglen) * ld + x);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  }
+};
+// epilogue: class-local row m -> input pixel (n, 2i+ph, 2j+pw); always accumulating (the caller zero-fills)
+struct EpiS2 {
+  float* C;
+  long ldc;
+  const float* bias;   // unused (interface symmetry)
+  int mode;            // 1
+  int cs;
+  int H, W, Hc, Wc, ph, pw;
+  __device__ __forceinline__ float* at(int m, int n) const {
+    const int hw = Hc * Wc;
+    const int img = m / hw, r = m - img * hw;
+    const int i = r / Wc, j = r - i * Wc;
+    return C + ((long)(img * H + 2 * i + ph) * W + 2 * j + pw) * ldc + n;
+  }
+  __device__ __forceinline__ void store(int m, int n, float v) const { *at(m, n) += v; }
+  __device__ __forceinline__ void add_partial(int m, int n, float v, bool) const { atomicAdd(at(m, n), v); }
+};
+
 // ---- wgrad A: A[m = (kh,kw,c)][k = output pixel] = x[n, ho*s-p+kh, wo*s-p+kw, c]; contiguous along m
 struct WgradX {
   static constexpr bool KCONTIG = false;

@@ -419,6 +419,34 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
 static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s) {
   const int M = g.N * g.H * g.W, K = g.KS * g.KS * g.Co;
   if (g.Co % 32 || g.C % 4) return AVVAD_EINVAL;
+  if (g.stride == 2) {
+    // parity-class decomposition (conv_ops.h): 4 small GEMMs over live taps only, accumulating into dx
+    if (!accumulate) hipLaunchKernelGGL(zero_f32, dim3(ew_grid((long)M * g.C)), dim3(256), 0, s, dx, (long)M * g.C);
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) {
+        convop::S2Class c;
+        c.ph = ph; c.pw = pw;
+        c.Hc = (g.H - ph + 1) / 2; c.Wc = (g.W - pw + 1) / 2;
+        c.kh0 = (ph + g.pad) & 1; c.kw0 = (pw + g.pad) & 1;
+        c.nkh = c.kh0 < g.KS ? (g.KS - c.kh0 + 1) / 2 : 0;
+        c.nkw = c.kw0 < g.KS ? (g.KS - c.kw0 + 1) / 2 : 0;
+        c.oh = (ph + g.pad - c.kh0) / 2; c.ow = (pw + g.pad - c.kw0) / 2;
+        const int Mc = g.N * c.Hc * c.Wc, ntap = c.nkh * c.nkw;
+        if (Mc <= 0 || ntap <= 0) continue;
+        if (ntap > 4) return AVVAD_EINVAL;
+        convop::Im2colDgradS2 a{dy, g, c, Mc};
+        convop::ColSegRows b{wd, g.C, g.C, ntap * g.Co, g.Co, {0, 0, 0, 0}};
+        for (int ia = 0; ia < c.nkh; ++ia)
+          for (int ib = 0; ib < c.nkw; ++ib)
+            b.rowbase[ia * c.nkw + ib] = ((c.kh0 + 2 * ia) * g.KS + (c.kw0 + 2 * ib)) * g.Co;
+        convop::EpiS2 e{dx, g.C, nullptr, 1, 1, g.H, g.W, c.Hc, c.Wc, ph, pw};
+        int rc;
+        if (g.C <= 64) rc = igemm::launch<128, 64>(a, b, e, Mc, g.C, ntap * g.Co, 1, s);
+        else rc = igemm::launch<128, 128>(a, b, e, Mc, g.C, ntap * g.Co, 1, s);
+        if (rc) return rc;
+      }
+    return AVVAD_OK;
+  }
   igemm::EpiStore e{dx, g.C, nullptr, accumulate ? 1 : 0};
   igemm::ColPlain<4> b{wd, g.C, g.C, K, 0};
   convop::Im2colDgrad a{dy, g, M};
