@@ -60,6 +60,11 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("N", "H", "W", "C", "Co", "KS", "stride", "pad")]
 
 
+class McbDesc(C.Structure):
+    _fields_ = [("rows", C.c_int), ("A", C.c_int), ("V", C.c_int), ("D", C.c_int), ("eps", C.c_float),
+                ("training", C.c_int), ("momentum", C.c_float), ("save_for_backward", C.c_int)]
+
+
 class LstmDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("In", C.c_int), ("H", C.c_int), ("lengths", FP),
                 ("save_for_backward", C.c_int)]
@@ -85,6 +90,9 @@ SIGNATURES = {
     "avvad_lstm_workspace": (C.c_size_t, [C.POINTER(LstmDesc)]),
     "avvad_lstm_layer_fwd": (C.c_int, [FP, FP, FP, FP, FP, FP, C.POINTER(LstmDesc), FP, C.c_size_t, FP]),
     "avvad_lstm_layer_bwd": (C.c_int, [FP, FP, FP, FP, FP, FP, FP, FP, FP, FP, C.POINTER(LstmDesc), FP, C.c_size_t, FP]),
+    "avvad_mcb_workspace": (C.c_size_t, [C.POINTER(McbDesc)]),
+    "avvad_mcb_fusion_fwd": (C.c_int, [FP] * 11 + [C.POINTER(McbDesc), FP, C.c_size_t, FP]),
+    "avvad_mcb_fusion_bwd": (C.c_int, [FP] * 12 + [C.POINTER(McbDesc), FP, C.c_size_t, FP]),
     "avvad_bce_masked": (C.c_int, [FP, FP, FP, FP, FP, C.c_int, C.c_int, C.c_int, C.c_float, FP]),
     "avvad_adam_step": (C.c_int, [FP, FP, FP, FP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, FP]),
     "avvad_copy_cols": (C.c_int, [FP, FP, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, FP]),

@@ -284,6 +284,49 @@ class TrunkFn(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads) + (None,) * (2 * n)
 
 
+# --------------------------------------------------------------------------- MCB fusion
+class McbFusionFn(torch.autograd.Function):
+    """audio (B,T,A), video (B,T,V) -> BatchNorm1d(L2norm(ssqrt(MCB(audio, video))))  (B,T,D)  (AV_Net.py:109-121)."""
+
+    @staticmethod
+    def forward(ctx, audio, video, h1, s1, h2, s2, bn_w, bn_b, rm, rv, eps, training, momentum):
+        audio, video = _dev(audio, "audio"), _dev(video, "video")
+        B, T, A = audio.shape
+        V = video.shape[-1]
+        D = bn_w.numel()
+        for t, n in ((h1, "h1"), (h2, "h2")):
+            if not t.is_cuda or t.dtype != torch.long:
+                raise L.AvvadError("%s must be an int64 GPU tensor" % n)
+        d = L.McbDesc(B * T, A, V, D, float(eps), int(training), float(momentum), 1)
+        ws = _ws(L.lib().avvad_mcb_workspace(C.byref(d)), audio.device)
+        out = torch.empty(B, T, D, dtype=torch.float32, device=audio.device)
+        L.check(L.lib().avvad_mcb_fusion_fwd(L.ptr(audio), L.ptr(video), L.ptr(h1), L.ptr(_dev(s1, "s1")), L.ptr(h2),
+                                             L.ptr(_dev(s2, "s2")), L.ptr(_dev(bn_w, "bn_w")), L.ptr(_dev(bn_b, "bn_b")),
+                                             L.ptr(rm), L.ptr(rv), L.ptr(out), C.byref(d), L.ptr(ws), ws.numel() * 4,
+                                             _stream()), "avvad_mcb_fusion_fwd")
+        ctx.save_for_backward(audio, video, h1, s1, h2, s2, bn_w, ws)
+        ctx.cfg = (float(eps), int(training), float(momentum))
+        ctx.prm = (bn_w, bn_b)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        audio, video, h1, s1, h2, s2, bn_w, ws = ctx.saved_tensors
+        B, T, A = audio.shape
+        V, D = video.shape[-1], bn_w.numel()
+        eps, training, momentum = ctx.cfg
+        d = L.McbDesc(B * T, A, V, D, eps, training, momentum, 1)
+        da = torch.empty_like(audio) if ctx.needs_input_grad[0] else None
+        dv = torch.empty_like(video) if ctx.needs_input_grad[1] else None
+        tg = [_grad_target(ctx.prm[0], ctx.needs_input_grad[6]), _grad_target(ctx.prm[1], ctx.needs_input_grad[7])]
+        L.check(L.lib().avvad_mcb_fusion_bwd(L.ptr(audio), L.ptr(video), L.ptr(h1), L.ptr(s1), L.ptr(h2), L.ptr(s2),
+                                             L.ptr(bn_w), L.ptr(_dev(dout, "dout")), L.ptr(da), L.ptr(dv), L.ptr(tg[0][0]),
+                                             L.ptr(tg[1][0]), C.byref(d), L.ptr(ws), ws.numel() * 4, _stream()),
+                "avvad_mcb_fusion_bwd")
+        dw, db = _finish_grads(ctx.prm, tg)
+        return da, dv, None, None, None, None, dw, db, None, None, None, None, None
+
+
 # --------------------------------------------------------------------------- loss
 class MaskedBceFn(torch.autograd.Function):
     """sum_b mean_{t<len_b} BCE-with-eps(logits, targets)  (models/utils.py:108-113 + train_AV_net.py:298-301)."""

@@ -1,0 +1,180 @@
+// bn_kernels.h -- BatchNorm building blocks over a row-major [M][C] fp32 matrix (C % 4 == 0, C <= BN_MAXC):
+// two-stage fp64 column reductions, statistics -> scale/shift, fused normalise(+residual)(+ReLU), and the
+// backward pair.  Shared by the ResNet trunk (BatchNorm2d over NHWC pixels) and the MCB fusion (BatchNorm1d
+// over (sequence, frame) rows).  Included into an anonymous namespace by each user.
+#pragma once
+#include "common.h"
+
+constexpr int BN_MAXC = 1024;
+constexpr int MAXC = BN_MAXC;
+constexpr int STAT_CHUNKS = 256;
+
+// ------------------------------------------------------------------ column reductions ([M][C] fp32 -> per-channel fp64 sums)
+// MODE 0: sum x, sum x^2           (batch statistics)
+// MODE 1: sum g, sum g*xhat  with g = dy * (ymask > 0 if ymask)   (BatchNorm backward)
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    col_reduce(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask,
+               const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C, long rows_per_chunk,
+               double* __restrict__ part) {
+  __shared__ double sm[256 * 8];
+  const int t = threadIdx.x;
+  const int Q = C >> 2, RL = 256 / Q;
+  const int q = t % Q, rl = t / Q;
+  double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+  float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+  if (MODE == 1) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = mean[q * 4 + j]; is[j] = invstd[q * 4 + j]; }
+  }
+  const long r0 = blockIdx.x * rows_per_chunk;
+  const long r1 = min(M, r0 + rows_per_chunk);
+  if (rl < RL)
+    for (long r = r0 + rl; r < r1; r += RL) {
+      const long o = r * C + q * 4;
+      const float4 v = *reinterpret_cast<const float4*>(x + o);
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += xv[j]; ss[j] += (double)xv[j] * xv[j]; }
+      } else {
+        const float4 d = *reinterpret_cast<const float4*>(dy + o);
+        float g[4] = {d.x, d.y, d.z, d.w};
+        if (ymask) {
+          const float4 y = *reinterpret_cast<const float4*>(ymask + o);
+          if (!(y.x > 0.f)) g[0] = 0.f;
+          if (!(y.y > 0.f)) g[1] = 0.f;
+          if (!(y.z > 0.f)) g[2] = 0.f;
+          if (!(y.w > 0.f)) g[3] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { s[j] += g[j]; ss[j] += (double)g[j] * ((xv[j] - mu[j]) * is[j]); }
+      }
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { sm[t * 8 + j] = s[j]; sm[t * 8 + 4 + j] = ss[j]; }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int cq = c >> 2, cj = c & 3;
+    double a = 0, b = 0;
+    for (int l = 0; l < RL; ++l) { a += sm[(l * Q + cq) * 8 + cj]; b += sm[(l * Q + cq) * 8 + 4 + cj]; }
+    part[((long)blockIdx.x * 2 + 0) * C + c] = a;
+    part[((long)blockIdx.x * 2 + 1) * C + c] = b;
+  }
+}
+
+// sum the per-chunk partials of channel c = blockIdx.x*32 + (tid&31): 8 chunk-lanes per channel, fixed order
+// (deterministic); every thread of the 256-thread block must call it; lanes tid < 32 get the totals.
+__device__ __forceinline__ void chunk_sums(const double* __restrict__ part, int nchunk, int C, double& s, double& ss) {
+  __shared__ double sm[2][8][32];
+  const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double a = 0, b = 0;
+  if (c < C)
+    for (int i = kl; i < nchunk; i += 8) { a += part[((long)i * 2 + 0) * C + c]; b += part[((long)i * 2 + 1) * C + c]; }
+  sm[0][kl][cl] = a; sm[1][kl][cl] = b;
+  __syncthreads();
+  s = 0; ss = 0;
+  if (kl == 0)
+    for (int k = 0; k < 8; ++k) { s += sm[0][k][cl]; ss += sm[1][k][cl]; }
+}
+
+// finalize batch statistics -> scale/shift (+ saved mean/invstd, running-stat update)
+__global__ void bn_finalize(const double* __restrict__ part, int nchunk, long M, int C, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, float* __restrict__ rm, float* __restrict__ rv, int training,
+                            float momentum, float eps, float* __restrict__ scale, float* __restrict__ shift,
+                            float* __restrict__ mean_o, float* __restrict__ invstd_o) {
+  double s = 0, ss = 0;
+  if (training) chunk_sums(part, nchunk, C, s, ss);
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if (c >= C || threadIdx.x >= 32) return;
+  float mean, var;
+  if (training) {
+    const double m = s / (double)M;
+    double v = ss / (double)M - m * m;
+    if (v < 0) v = 0;
+    mean = (float)m; var = (float)v;
+    const double unb = M > 1 ? v * (double)M / (double)(M - 1) : v;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * mean;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+  } else {
+    mean = rm[c]; var = rv[c];
+  }
+  const float is = 1.0f / sqrtf(var + eps);
+  const float sc = gamma[c] * is;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  mean_o[c] = mean;
+  invstd_o[c] = is;
+}
+
+// finalize BatchNorm backward sums -> dgamma/dbeta (accumulated) and the apply coefficients
+//   dx = k0 * (g - k1 - xhat * k2)
+__global__ void bn_bwd_finalize(const double* __restrict__ part, int nchunk, long M, int C, const float* __restrict__ gamma,
+                                const float* __restrict__ invstd, int training, float* __restrict__ dgamma,
+                                float* __restrict__ dbeta, float* __restrict__ coef) {
+  double s = 0, ss = 0;
+  chunk_sums(part, nchunk, C, s, ss);
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
+  if (c >= C || threadIdx.x >= 32) return;
+  if (dbeta) dbeta[c] += (float)s;
+  if (dgamma) dgamma[c] += (float)ss;
+  coef[c] = gamma[c] * invstd[c];
+  coef[MAXC + c] = training ? (float)(s / (double)M) : 0.f;
+  coef[2 * MAXC + c] = training ? (float)(ss / (double)M) : 0.f;
+}
+
+// ------------------------------------------------------------------ fused elementwise (16-byte accesses, C % 4 == 0)
+__device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return fmaf(x, sc, sh); }
+
+// y = [relu]( x*scale+shift  [+ idn | + idn*iscale+ishift] )
+__global__ void bn_act(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+                       const float* __restrict__ idn, const float* __restrict__ iscale, const float* __restrict__ ishift,
+                       float* __restrict__ y, long nquad, int C, int relu) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquad; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    float o[4] = {bn_affine(v.x, sc.x, sh.x), bn_affine(v.y, sc.y, sh.y), bn_affine(v.z, sc.z, sh.z), bn_affine(v.w, sc.w, sh.w)};
+    if (idn) {
+      const float4 d = reinterpret_cast<const float4*>(idn)[i];
+      if (iscale) {
+        const float4 a = *reinterpret_cast<const float4*>(iscale + c), b = *reinterpret_cast<const float4*>(ishift + c);
+        o[0] += bn_affine(d.x, a.x, b.x); o[1] += bn_affine(d.y, a.y, b.y);
+        o[2] += bn_affine(d.z, a.z, b.z); o[3] += bn_affine(d.w, a.w, b.w);
+      } else { o[0] += d.x; o[1] += d.y; o[2] += d.z; o[3] += d.w; }
+    }
+    if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+// dx = k0*(g - k1 - xhat*k2), g = dy*(ymask>0);  optionally also writes g (identity branch of the residual)
+// (dx may alias dy: each element is read, then written, by the same thread)
+__global__ void bn_bwd_apply(const float* __restrict__ x, const float* dy, const float* __restrict__ ymask,
+                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
+                             float* dx, float* gout, long nquad, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquad; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)((i * 4) % C);
+    const float4 xv = reinterpret_cast<const float4*>(x)[i];
+    const float4 d = reinterpret_cast<const float4*>(dy)[i];
+    float g[4] = {d.x, d.y, d.z, d.w};
+    if (ymask) {
+      const float4 y = reinterpret_cast<const float4*>(ymask)[i];
+      if (!(y.x > 0.f)) g[0] = 0.f;
+      if (!(y.y > 0.f)) g[1] = 0.f;
+      if (!(y.z > 0.f)) g[2] = 0.f;
+      if (!(y.w > 0.f)) g[3] = 0.f;
+    }
+    const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    float o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float xh = (xs[j] - mean[c + j]) * invstd[c + j];
+      o[j] = coef[c + j] * (g[j] - coef[MAXC + c + j] - xh * coef[2 * MAXC + c + j]);
+    }
+    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if (gout) reinterpret_cast<float4*>(gout)[i] = make_float4(g[0], g[1], g[2], g[3]);
+  }
+}
+

@@ -1,0 +1,214 @@
+// mcb.hip -- multimodal compact bilinear fusion of DeepVAD_AV (use_mcb=True), forward and backward.
+//
+// Replaces, per (sequence, frame) row (reference packages/models/AV_Net.py:109-121 and
+// packages/models/compact_bilinear_pooling.py:7-27,140-220):
+//   y  = irfft(rfft(psi(audio, h1, s1)) * rfft(psi(video, h2, s2)))      count sketch + circular convolution
+//   z  = sign(y) * sqrt(|y| + eps)                                       signed square root
+//   y2 = z / ||z||_2  (norm over the WHOLE tensor, detached)             L2 normalisation
+//   out = BatchNorm1d(D, eps)(y2)   statistics over all (sequence, frame) rows
+//
+// The FFT product of the reference is a circular convolution of two length-D sketches; at D = 1024 that is
+// 1 M MACs per row -- 2 GFLOP for 1024 rows, ~0.5 % of the trunk -- so it is evaluated directly in LDS
+// (both sketches resident, thread j owns outputs j, j+256, ...: the shifted operand is read at consecutive
+// addresses, the other one is a broadcast), which is exact in fp32 order-of-magnitude terms and needs no
+// transform tables.  The backward is the true gradient (two circular correlations), like the reference's
+// hand-written backward.
+#include "common.h"
+
+namespace {
+
+#include "bn_kernels.h"
+
+constexpr int MAXD = 2048;
+
+static inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
+
+// count sketch of one row into LDS: p[h[i]] += s[i] * x[i]
+__device__ __forceinline__ void sketch_row(const float* __restrict__ x, const int64_t* __restrict__ h,
+                                           const float* __restrict__ s, int n, float* p) {
+  for (int i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&p[(int)h[i]], s[i] * x[i]);
+}
+
+__global__ void __launch_bounds__(256)
+    mcb_fwd_kernel(const float* __restrict__ a, const float* __restrict__ v, const int64_t* __restrict__ h1,
+                   const float* __restrict__ s1, const int64_t* __restrict__ h2, const float* __restrict__ s2,
+                   float* __restrict__ y, int A, int V, int D) {
+  __shared__ float px[MAXD], py[MAXD];
+  const int row = blockIdx.x;
+  for (int j = threadIdx.x; j < D; j += 256) { px[j] = 0.f; py[j] = 0.f; }
+  __syncthreads();
+  sketch_row(a + (long)row * A, h1, s1, A, px);
+  sketch_row(v + (long)row * V, h2, s2, V, py);
+  __syncthreads();
+  for (int j0 = threadIdx.x; j0 < D; j0 += 1024) {   // 4 outputs per thread per pass
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < D; ++i) {
+      const float xi = px[i];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        int idx = j0 + u * 256 - i;
+        if (idx < 0) idx += D;
+        if (j0 + u * 256 < D) acc[u] = fmaf(xi, py[idx], acc[u]);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (j0 + u * 256 < D) y[(long)row * D + j0 + u * 256] = acc[u];
+  }
+}
+
+// da[i] = s1[i] * sum_j dy[j] py[(j - h1[i]) mod D],  dv likewise with px
+__global__ void __launch_bounds__(256)
+    mcb_bwd_kernel(const float* __restrict__ a, const float* __restrict__ v, const int64_t* __restrict__ h1,
+                   const float* __restrict__ s1, const int64_t* __restrict__ h2, const float* __restrict__ s2,
+                   const float* __restrict__ dy, float* __restrict__ da, float* __restrict__ dv, int A, int V, int D) {
+  __shared__ float px[MAXD], py[MAXD], g[MAXD];
+  const int row = blockIdx.x;
+  for (int j = threadIdx.x; j < D; j += 256) { px[j] = 0.f; py[j] = 0.f; g[j] = dy[(long)row * D + j]; }
+  __syncthreads();
+  sketch_row(a + (long)row * A, h1, s1, A, px);
+  sketch_row(v + (long)row * V, h2, s2, V, py);
+  __syncthreads();
+  // only the A (resp. V) sketch buckets that are actually hit need a gradient: one output per input channel
+  for (int i = threadIdx.x; i < A + V; i += 256) {
+    const bool isa = i < A;
+    const int c = isa ? i : i - A;
+    const int hb = (int)(isa ? h1[c] : h2[c]);
+    const float* other = isa ? py : px;
+    float acc = 0.f;
+    int idx = D - hb;           // (j - hb) mod D at j = 0
+    if (idx >= D) idx -= D;
+    for (int j = 0; j < D; ++j) {
+      acc = fmaf(g[j], other[idx], acc);
+      if (++idx == D) idx = 0;
+    }
+    if (isa) { if (da) da[(long)row * A + c] = s1[c] * acc; }
+    else if (dv) dv[(long)row * V + c] = s2[c] * acc;
+  }
+}
+
+// z = sign(y) sqrt(|y| + eps); sumsq += sum z^2 (fp64)
+__global__ void __launch_bounds__(256)
+    ssqrt_kernel(const float* __restrict__ y, float* __restrict__ z, double* __restrict__ sumsq, long n, float eps) {
+  __shared__ double sm[256];
+  double acc = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = y[i];
+    const float r = sqrtf(fabsf(v) + eps);
+    const float o = v > 0.f ? r : (v < 0.f ? -r : 0.f);
+    z[i] = o;
+    acc += (double)o * o;
+  }
+  sm[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(sumsq, sm[0]);
+}
+__global__ void zero_d(double* p) { *p = 0.0; }
+__global__ void scale_by_norm(const float* __restrict__ z, const double* __restrict__ sumsq, float* __restrict__ y2, long n) {
+  const float inv = (float)(1.0 / sqrt(*sumsq));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y2[i] = z[i] * inv;
+}
+// dY = dY2 / norm * d(signed sqrt)/dy,   d/dy = 0.5 / sqrt(|y| + eps) for y != 0, 0 at y == 0
+__global__ void ssqrt_bwd(const float* __restrict__ y, const double* __restrict__ sumsq, float* __restrict__ g, long n, float eps) {
+  const float inv = (float)(1.0 / sqrt(*sumsq));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = y[i];
+    g[i] = v != 0.f ? g[i] * inv * 0.5f / sqrtf(fabsf(v) + eps) : 0.f;
+  }
+}
+
+struct Ws {
+  float *Y, *Z, *Y2, *G, *scale, *shift, *mean, *invstd, *coef;
+  double *part, *sumsq;
+  size_t total;
+};
+static Ws carve(const avvad_mcb_desc* d, float* base) {
+  Ws w;
+  size_t off = 0;
+  auto take = [&](size_t n) { size_t o = off; off += align_up(n, 64); return base ? base + o : (float*)nullptr; };
+  const size_t n = (size_t)d->rows * d->D;
+  w.Y = take(n); w.Z = take(n); w.Y2 = take(n); w.G = take(n);
+  w.scale = take(d->D); w.shift = take(d->D); w.mean = take(d->D); w.invstd = take(d->D);
+  w.coef = take(3 * BN_MAXC);
+  w.part = (double*)take((size_t)STAT_CHUNKS * 2 * BN_MAXC * 2);
+  w.sumsq = (double*)take(64);
+  w.total = off;
+  return w;
+}
+static bool ok_desc(const avvad_mcb_desc* d) {
+  return d && d->rows > 0 && d->A > 0 && d->V > 0 && d->D >= 4 && d->D <= BN_MAXC && d->D % 4 == 0;
+}
+struct Chunks { int n; long per; };
+static Chunks chunks(long M, int C) {
+  const int RL = 256 / (C / 4) > 0 ? 256 / (C / 4) : 1;
+  long per = (M + STAT_CHUNKS - 1) / STAT_CHUNKS;
+  per = (per + RL - 1) / RL * RL;
+  if (per < RL) per = RL;
+  Chunks c;
+  c.per = per;
+  c.n = cdiv(M, per);
+  return c;
+}
+
+}  // namespace
+
+extern "C" size_t avvad_mcb_workspace(const avvad_mcb_desc* d) {
+  if (!ok_desc(d)) return 0;
+  return carve(d, nullptr).total * sizeof(float);
+}
+
+extern "C" int avvad_mcb_fusion_fwd(const float* audio, const float* video, const int64_t* h1, const float* s1,
+                                    const int64_t* h2, const float* s2, const float* bn_w, const float* bn_b, float* bn_rm,
+                                    float* bn_rv, float* out, const avvad_mcb_desc* d, void* wsv, size_t ws_bytes,
+                                    avvad_stream_t sv) {
+  AVVAD_ENTER();
+  if (!audio || !video || !h1 || !s1 || !h2 || !s2 || !bn_w || !bn_b || !bn_rm || !bn_rv || !out || !wsv || !ok_desc(d))
+    return AVVAD_EINVAL;
+  hipStream_t s = (hipStream_t)sv;
+  Ws w = carve(d, (float*)wsv);
+  if (ws_bytes < w.total * sizeof(float)) return AVVAD_EWORKSPACE;
+  const long n = (long)d->rows * d->D;
+  hipLaunchKernelGGL(mcb_fwd_kernel, dim3(d->rows), dim3(256), 0, s, audio, video, h1, s1, h2, s2, w.Y, d->A, d->V, d->D);
+  hipLaunchKernelGGL(zero_d, dim3(1), dim3(1), 0, s, w.sumsq);
+  hipLaunchKernelGGL(ssqrt_kernel, dim3(ew_grid(n) > 1024 ? 1024 : ew_grid(n)), dim3(256), 0, s, w.Y, w.Z, w.sumsq, n, d->eps);
+  hipLaunchKernelGGL(scale_by_norm, dim3(ew_grid(n)), dim3(256), 0, s, w.Z, w.sumsq, w.Y2, n);
+  const Chunks c = chunks(d->rows, d->D);
+  if (d->training)
+    hipLaunchKernelGGL(col_reduce<0>, dim3(c.n), dim3(256), 0, s, w.Y2, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (long)d->rows, d->D, c.per, w.part);
+  hipLaunchKernelGGL(bn_finalize, dim3(cdiv(d->D, 32)), dim3(256), 0, s, w.part, c.n, (long)d->rows, d->D, bn_w, bn_b, bn_rm,
+                     bn_rv, d->training, d->momentum, d->eps, w.scale, w.shift, w.mean, w.invstd);
+  hipLaunchKernelGGL(bn_act, dim3(ew_grid(n / 4)), dim3(256), 0, s, w.Y2, w.scale, w.shift, (const float*)nullptr,
+                     (const float*)nullptr, (const float*)nullptr, out, n / 4, d->D, 0);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_mcb_fusion_bwd(const float* audio, const float* video, const int64_t* h1, const float* s1,
+                                    const int64_t* h2, const float* s2, const float* bn_w, const float* dout, float* daudio,
+                                    float* dvideo, float* dbn_w, float* dbn_b, const avvad_mcb_desc* d, void* wsv,
+                                    size_t ws_bytes, avvad_stream_t sv) {
+  AVVAD_ENTER();
+  if (!audio || !video || !h1 || !s1 || !h2 || !s2 || !bn_w || !dout || !wsv || !ok_desc(d)) return AVVAD_EINVAL;
+  hipStream_t s = (hipStream_t)sv;
+  Ws w = carve(d, (float*)wsv);
+  if (ws_bytes < w.total * sizeof(float)) return AVVAD_EWORKSPACE;
+  const long n = (long)d->rows * d->D;
+  const Chunks c = chunks(d->rows, d->D);
+  hipLaunchKernelGGL(col_reduce<1>, dim3(c.n), dim3(256), 0, s, w.Y2, dout, (const float*)nullptr, w.mean, w.invstd,
+                     (long)d->rows, d->D, c.per, w.part);
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(d->D, 32)), dim3(256), 0, s, w.part, c.n, (long)d->rows, d->D, bn_w, w.invstd,
+                     d->training, dbn_w, dbn_b, w.coef);
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid(n / 4)), dim3(256), 0, s, w.Y2, dout, (const float*)nullptr, w.mean, w.invstd,
+                     w.coef, w.G, (float*)nullptr, n / 4, d->D);
+  hipLaunchKernelGGL(ssqrt_bwd, dim3(ew_grid(n)), dim3(256), 0, s, w.Y, w.sumsq, w.G, n, d->eps);
+  if (daudio || dvideo)
+    hipLaunchKernelGGL(mcb_bwd_kernel, dim3(d->rows), dim3(256), 0, s, audio, video, h1, s1, h2, s2, w.G, daudio, dvideo, d->A,
+                       d->V, d->D);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}

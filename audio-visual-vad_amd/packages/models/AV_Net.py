@@ -6,7 +6,6 @@ waveform (B, quantization_channel, L) whose encoder output (B,Bn,T) is fused wit
 import torch
 import torch.nn as nn
 
-from avvad import AvvadError
 from avvad import nn as avnn
 from avvad import ops
 from packages.models.compact_bilinear_pooling import CompactBilinearPooling
@@ -51,8 +50,14 @@ class DeepVAD_AV(nn.Module):
         if hasattr(self, "wavenet_en"):
             audio = ops.TransposeLast2Fn.apply(self.wavenet_en(audio))            # (B,T,Bn)
         if self.use_mcb:
-            raise AvvadError("use_mcb=True: compact bilinear pooling has no HIP kernel yet (SURVEY 8f N2); "
-                             "the concat fusion (use_mcb=False) is the supported path -- refusing to fall back")
-        y = ops.ConcatColsFn.apply(audio, feats)
+            # sketch + circular convolution -> signed sqrt -> whole-tensor L2 norm -> BatchNorm1d, fused (csrc/mcb.hip)
+            bn = self.mcb_bn
+            y = ops.McbFusionFn.apply(audio, feats, self.mcb.sketch1.h, self.mcb.sketch1.s, self.mcb.sketch2.h,
+                                      self.mcb.sketch2.s, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                      self.eps, self.training, bn.momentum)
+            if self.training:
+                bn.num_batches_tracked += 1
+        else:
+            y = ops.ConcatColsFn.apply(audio, feats)
         out = ops.lstm_stack(y, lengths, self.lstm_merged)
         return ops.LinearFn.apply(out, self.vad_merged.weight, self.vad_merged.bias)

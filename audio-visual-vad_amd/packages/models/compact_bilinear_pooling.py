@@ -30,7 +30,7 @@ class CountSketch(nn.Module):
         return self
 
     def forward(self, x):
-        raise AvvadError("CountSketch: no HIP kernel yet (SURVEY 8f N2); refusing to fall back to PyTorch")
+        raise AvvadError("CountSketch is a buffer container here: the sketch runs inside avvad.ops.McbFusionFn (no PyTorch fallback)")
 
 
 class CompactBilinearPooling(nn.Module):
@@ -43,4 +43,4 @@ class CompactBilinearPooling(nn.Module):
         self.force_cpu_scatter_add = force_cpu_scatter_add
 
     def forward(self, x, y=None):
-        raise AvvadError("CompactBilinearPooling: no HIP kernel yet (SURVEY 8f N2); refusing to fall back to PyTorch")
+        raise AvvadError("CompactBilinearPooling is a buffer container here: use DeepVAD_AV(use_mcb=True) (fused HIP path, no fallback)")

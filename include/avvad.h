@@ -199,6 +199,33 @@ int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const float* w_hh, c
                          avvad_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * Multimodal compact bilinear fusion + signed sqrt + whole-tensor L2 normalisation + BatchNorm1d
+ * Replaces: the use_mcb branch of DeepVAD_AV.forward, packages/models/AV_Net.py:109-121, i.e.
+ *   CompactBilinearPooling (packages/models/compact_bilinear_pooling.py:7-27,140-220: count sketches
+ *   psi(x,h,s)[h_i] += s_i x_i, circular convolution of the two sketches) -> sign(y)sqrt(|y|+eps) ->
+ *   y / ||y||_2 (detached norm of the whole tensor) -> BatchNorm1d(D, eps) over all rows.
+ * audio [rows][A], video [rows][V], out [rows][D]; rows = B*T; h1/h2 int64 bucket per input channel
+ * (values in [0, D)), s1/s2 = +-1.  D % 4 == 0, D <= 1024.  bwd accumulates (+=) dbn_w / dbn_b and
+ * overwrites daudio / dvideo (either may be NULL).
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int rows, A, V, D;
+  float eps;      /* used for the signed sqrt AND as the BatchNorm eps (AV_Net.py:49,114) */
+  int training;
+  float momentum;
+  int save_for_backward;
+} avvad_mcb_desc;
+size_t avvad_mcb_workspace(const avvad_mcb_desc* d);
+int avvad_mcb_fusion_fwd(const float* audio, const float* video, const int64_t* h1, const float* s1,
+                         const int64_t* h2, const float* s2, const float* bn_w, const float* bn_b,
+                         float* bn_rm, float* bn_rv, float* out, const avvad_mcb_desc* d, void* ws,
+                         size_t ws_bytes, avvad_stream_t s);
+int avvad_mcb_fusion_bwd(const float* audio, const float* video, const int64_t* h1, const float* s1,
+                         const int64_t* h2, const float* s2, const float* bn_w, const float* dout,
+                         float* daudio, float* dvideo, float* dbn_w, float* dbn_b,
+                         const avvad_mcb_desc* d, void* ws, size_t ws_bytes, avvad_stream_t s);
+
+/* ------------------------------------------------------------------------
  * Masked BCE-with-eps loss, summed over sequences
  * Replaces: binary_cross_entropy packages/models/utils.py:108-113 and its caller
  *   loop scripts/train_AV_net.py:298-301  (per-sequence mean over valid frames

@@ -306,8 +306,48 @@ def test_av_net_golden_concat():
     _report("AV net eval", m(a, v, lens), g["y_eval"], 1e-4)
     m.train()
     _report("AV net train", m(a, v, torch.LongTensor(lens).to(DEV)), g["y_train"], 1e-4)
-    with pytest.raises(Exception):
-        DeepVAD_AV(2, 16, 1, use_mcb=True).to(DEV)(a, v, lens)      # no silent fallback
+
+
+def test_av_net_mcb_fusion_vs_oracle():
+    """use_mcb=True (the reference's default fusion): count sketch + circular convolution + signed sqrt + whole-tensor
+    L2 norm + BatchNorm1d(eps=1e-8), forward and all gradients, train and eval mode.  The reference forward cannot
+    run on torch 2.x (torch.rfft): the oracle restates it with torch.fft and is pinned against the naive
+    outer-product sketch (tests/test_oracle_golden.py) -- "parity unpinned" by reference outputs."""
+    from oracle import head, models
+    from packages.models.AV_Net import DeepVAD_AV
+    from packages.models.utils import batch_binary_cross_entropy
+    torch.manual_seed(2)
+    m = DeepVAD_AV(1, 32, 1, use_mcb=True, eps=1e-8)
+    B, Tn = 3, 4
+    a = torch.randn(B, Tn, 513)
+    v = torch.randn(B, Tn, 67, 67)
+    tgt = (torch.rand(B, Tn, 1) > 0.5).float()
+    lens = [4, 2, 3]
+    for training in (False, True):
+        sd = {k: (t.detach().clone().requires_grad_(True) if t.dtype == torch.float32 and "running" not in k and ".s" not in k[-2:]
+                  else t.detach().clone()) for k, t in m.state_dict().items()}
+        ar = a.clone().requires_grad_(True)
+        ref = models.av_net(sd, ar, v, lens, 1, use_mcb=True, eps=1e-8, training=training)
+        ref_loss = head.batch_loss(ref, tgt, lens, 1e-8)
+        ref_loss.backward()
+        mg = DeepVAD_AV(1, 32, 1, use_mcb=True, eps=1e-8)
+        mg.load_state_dict(m.state_dict())
+        mg = mg.to(DEV).train(training)
+        ag = a.clone().to(DEV).requires_grad_(True)
+        y = mg(ag, v.to(DEV), lens)
+        tag = "AV+MCB %s" % ("train" if training else "eval")
+        _report(tag + " logits", y, ref, 1e-4)
+        loss = batch_binary_cross_entropy(y, tgt.to(DEV), lens, 1e-8)
+        loss.backward()
+        _report_grad(tag + " d/d audio", ag.grad, ar.grad, 2.0, 2e-2)
+        for k in ("mcb_bn.weight", "mcb_bn.bias", "lstm_merged.weight_ih_l0", "features.7.1.conv2.weight", "features.0.weight"):
+            _report_grad(tag + " d/d" + k, dict(mg.named_parameters())[k].grad, sd[k].grad, 2.0, 2e-2)
+        if training:
+            _report(tag + " running_var", mg.mcb_bn.running_var, sd["mcb_bn.running_var"], 1e-6, 1e-4)
+            assert int(mg.mcb_bn.num_batches_tracked) == 1
+    from avvad import AvvadError
+    with pytest.raises(AvvadError):
+        mg.mcb(ag, ag)            # the bare containers have no stand-alone kernel and no fallback
 
 
 def test_av_wavenet_end_to_end_vs_oracle():
