@@ -7,6 +7,13 @@
 // wgrad   : M = KH*KW*C,        N = Co, K = N*Ho*Wo   A = x gathered^T   B = dy[(pixel)][co]
 // C and Co are multiples of 32 for every trunk conv but the stem (C = 1),
 // which has its own scalar-gather functors.
+//
+// K ORDER.  The contraction index is walked as (32-channel chunk, tap, channel-in-chunk): consecutive BK=32
+// K-tiles are the 9 taps of ONE 128-byte channel chunk, i.e. the same few input pixels shifted by one -- the
+// re-reads hit L1/L2.  With the textbook (tap, channel) order a tap's re-read comes C/32 K-tiles later, by
+// which time an XCD's 64 resident workgroups have streamed > 4 MiB through its L2: rocprof showed the forward
+// kernel fetching 7.5x its input from beyond L2 (profiles/r01_pmc_fetch_size_per_kernel.csv).  Weights stay in
+// the plain packed layouts; the B functors remap rows.
 #pragma once
 #include "igemm.h"
 
@@ -36,9 +43,10 @@ struct Im2colFwd {
     return c;
   }
   __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
-    const int seg = k0 / g.C;  // wave-uniform: C % 32 == 0
-    const int c0 = k0 - seg * g.C + kin;
-    const int kh = seg / g.KS, kw = seg - kh * g.KS;
+    const int T = g.KS * g.KS, q = k0 >> 5;  // wave-uniform (k0 % 32 == 0, C % 32 == 0)
+    const int cc = q / T, tap = q - cc * T;
+    const int c0 = cc * 32 + kin;
+    const int kh = tap / g.KS, kw = tap - kh * g.KS;
     const int hi = c.hi0 + kh, wi = c.wi0 + kw;
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (c.base >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
@@ -68,9 +76,10 @@ struct Im2colDgrad {
     return c;
   }
   __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
-    const int seg = k0 / g.Co;
-    const int c0 = k0 - seg * g.Co + kin;
-    const int kh = seg / g.KS, kw = seg - kh * g.KS;
+    const int T = g.KS * g.KS, q = k0 >> 5;
+    const int cc = q / T, tap = q - cc * T;
+    const int c0 = cc * 32 + kin;
+    const int kh = tap / g.KS, kw = tap - kh * g.KS;
     const int th = c.hp - kh, tw = c.wp - kw;
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (c.base < 0 || th < 0 || tw < 0) return;
@@ -116,8 +125,9 @@ struct Im2colDgradS2 {
     return x;
   }
   __device__ __forceinline__ void load(const Ctx& x, int, int k0, int kin, float* v) const {
-    const int seg = k0 / g.Co;
-    const int c0 = k0 - seg * g.Co + kin;
+    const int ntap = c.nkh * c.nkw, q = k0 >> 5;
+    const int cc = q / ntap, seg = q - cc * ntap;
+    const int c0 = cc * 32 + kin;
     const int a = seg / c.nkw, b = seg - a * c.nkw;
     const int ho = x.i + c.oh - a, wo = x.j + c.ow - b;
     v[0] = v[1] = v[2] = v[3] = 0.f;
@@ -127,22 +137,23 @@ struct Im2colDgradS2 {
     }
   }
 };
-// weight rows of the live taps: element (k, x) = p[(rowbase[k / seglen] + k % seglen) * ld + x]
+// weight rows of the live taps in (chunk, tap, channel) K order:
+//   k = (cc*ntap + tap)*32 + r  ->  row rowbase[tap] + cc*32 + r
 struct ColSegRows {
   static constexpr bool KCONTIG = false;
   static constexpr int VEC = 4;
   typedef igemm::NoCtx Ctx;
   const float* p;
   long ld;
-  int X, K, seglen;
+  int X, K, ntap;
   int rowbase[4];
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
   __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (k < K && x < X) {
-      const int seg = k / seglen;
-      const float4 t = *reinterpret_cast<const float4*>(p + (long)(rowbase[seg] + k - seg * seglen) * ld + x);
+      const int q = k >> 5, cc = q / ntap, seg = q - cc * ntap;
+      const float4 t = *reinterpret_cast<const float4*>(p + (long)(rowbase[seg] + cc * 32 + (k & 31)) * ld + x);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
   }
@@ -165,7 +176,43 @@ struct EpiS2 {
   __device__ __forceinline__ void add_partial(int m, int n, float v, bool) const { atomicAdd(at(m, n), v); }
 };
 
-// ---- wgrad A: A[m = (kh,kw,c)][k = output pixel] = x[n, ho*s-p+kh, wo*s-p+kw, c]; contiguous along m
+// packed weights [(tap, ch)][x] read in (chunk, tap, channel) K order: k = (cc*T + tap)*32 + r -> row tap*C + cc*32 + r
+struct ColTapRows {
+  static constexpr bool KCONTIG = false;
+  static constexpr int VEC = 4;
+  typedef igemm::NoCtx Ctx;
+  const float* p;
+  long ld;
+  int X, K, C, T;
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
+  __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
+    const int k = k0 + kin;
+    v[0] = v[1] = v[2] = v[3] = 0.f;
+    if (k < K && x < X) {
+      const int q = k >> 5, cc = q / T, tap = q - cc * T;
+      const float4 t = *reinterpret_cast<const float4*>(p + (long)(tap * C + cc * 32 + (k & 31)) * ld + x);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+  }
+};
+// wgrad epilogue: GEMM row m' = (cc*T + tap)*32 + r (chunk-major, see WgradX) -> packed row tap*C + cc*32 + r; atomic
+struct EpiWgrad {
+  float* C;
+  long ldc;
+  const float* bias;  // unused
+  int mode;           // 2
+  int cs;
+  int Cch, T;
+  __device__ __forceinline__ float* at(int m, int n) const {
+    const int q = m >> 5, cc = q / T, tap = q - cc * T;
+    return C + (long)(tap * Cch + cc * 32 + (m & 31)) * ldc + n;
+  }
+  __device__ __forceinline__ void store(int m, int n, float v) const { atomicAdd(at(m, n), v); }
+  __device__ __forceinline__ void add_partial(int m, int n, float v, bool) const { atomicAdd(at(m, n), v); }
+};
+
+// ---- wgrad A: A[m][k = output pixel] = x[n, ho*s-p+kh, wo*s-p+kw, c] with m = (cc*T + tap)*32 + r, c = cc*32 + r:
+// a 128-row M tile is 4 taps of one 32-channel chunk, so the taps' overlapping pixel reads share L1/L2 lines
 struct WgradX {
   static constexpr bool KCONTIG = false;
   static constexpr int VEC = 4;
@@ -176,10 +223,11 @@ struct WgradX {
   __device__ __forceinline__ Ctx prep(int m) const {
     Ctx c;
     if (m >= M) { c.kh = -1; c.kw = c.c = 0; return c; }
-    const int seg = m / g.C;
-    c.c = m - seg * g.C;
-    c.kh = seg / g.KS;
-    c.kw = seg - c.kh * g.KS;
+    const int T = g.KS * g.KS, q = m >> 5;
+    const int cc = q / T, tap = q - cc * T;
+    c.c = cc * 32 + (m & 31);
+    c.kh = tap / g.KS;
+    c.kw = tap - c.kh * g.KS;
     return c;
   }
   __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {

@@ -236,12 +236,13 @@ static inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4
 static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s) {
   const int M = g.N * g.Ho * g.Wo, K = g.KS * g.KS * g.C;
   igemm::EpiStore e{y, g.Co, nullptr, 0};
-  igemm::ColPlain<4> b{wf, g.Co, g.Co, K, 0};
   if (g.C == 1) {
+    igemm::ColPlain<4> b{wf, g.Co, g.Co, K, 0};
     convop::StemFwd a{x, g, M, K};
     return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
   }
   if (g.C % 32 || g.Co % 4) return AVVAD_EINVAL;
+  convop::ColTapRows b{wf, g.Co, g.Co, K, g.C, g.KS * g.KS};
   convop::Im2colFwd a{x, g, M};
   if (g.Co <= 64) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s);
@@ -266,7 +267,7 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
         if (Mc <= 0 || ntap <= 0) continue;
         if (ntap > 4) return AVVAD_EINVAL;
         convop::Im2colDgradS2 a{dy, g, c, Mc};
-        convop::ColSegRows b{wd, g.C, g.C, ntap * g.Co, g.Co, {0, 0, 0, 0}};
+        convop::ColSegRows b{wd, g.C, g.C, ntap * g.Co, ntap, {0, 0, 0, 0}};
         for (int ia = 0; ia < c.nkh; ++ia)
           for (int ib = 0; ib < c.nkw; ++ib)
             b.rowbase[ia * c.nkw + ib] = ((c.kh0 + 2 * ia) * g.KS + (c.kw0 + 2 * ib)) * g.Co;
@@ -279,7 +280,7 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
     return AVVAD_OK;
   }
   igemm::EpiStore e{dx, g.C, nullptr, accumulate ? 1 : 0};
-  igemm::ColPlain<4> b{wd, g.C, g.C, K, 0};
+  convop::ColTapRows b{wd, g.C, g.C, K, g.Co, g.KS * g.KS};
   convop::Im2colDgrad a{dy, g, M};
   if (g.C <= 64) return igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s);
   return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s);
@@ -288,14 +289,16 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
 static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s) {
   const int M = g.KS * g.KS * g.C, K = g.N * g.Ho * g.Wo;
   hipLaunchKernelGGL(zero_f32, dim3(ew_grid((long)M * g.Co)), dim3(256), 0, s, pk, (long)M * g.Co);
-  igemm::EpiStore e{pk, g.Co, nullptr, 2};
   igemm::ColPlain<4> b{dy, g.Co, g.Co, K, 0};
   const int ktiles = cdiv(K, igemm::BK);
   if (g.C == 1) {
+    igemm::EpiStore e{pk, g.Co, nullptr, 2};
     convop::StemWgradX a{x, g, M, K};
     int split = 1024; if (split > ktiles) split = ktiles;
     return igemm::launch<64, 64>(a, b, e, M, g.Co, K, split, s);
   }
+  if (g.C % 32) return AVVAD_EINVAL;
+  convop::EpiWgrad e{pk, g.Co, nullptr, 2, 1, g.C, g.KS * g.KS};
   convop::WgradX a{x, g, M, K};
   const bool small = g.Co <= 64;
   const int nb = cdiv(M, 128) * cdiv(g.Co, small ? 64 : 128);
