@@ -31,6 +31,9 @@ W0 = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in ran
           en_dilation_channel=32, en_bottleneck_width=256, en_pool_kernel_size=T_FRAMES, use_bias=True)
 RF = 2048
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
+# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --no-extras`, dominant kernel, per
+# launch: FETCH_SIZE 95,320 KB x 2 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE 55,467 KB
+TRAFFIC_PER_LAUNCH_BYTES = int((2 * 95320 + 55467) * 1024)
 
 
 def make_inputs(torch, n_seq, seed, device):
@@ -60,9 +63,11 @@ def trunk_conv_shapes(n):
 
 def roofline_probe(torch, n_frames, reps=5):
     """Per-launch duration (HIP events on the launch stream) of the dominant kernel: the fp32-MFMA
-    implicit-GEMM convolution igemm::kernel<128,128,Im2colFwd,ColPlain<4>,EpiStore>, i.e. the forward of
-    every trunk conv with Cout >= 128 (15 launches per step).  achieved = algorithmic FLOPs of those
-    launches (2*N*Ho*Wo*Co*KS^2*C each) / their summed duration."""
+    implicit-GEMM convolution igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,EpiStore>, i.e. the forward
+    of every trunk conv with Cout >= 128 (15 launches per step).  achieved = algorithmic FLOPs of those
+    launches (2*N*Ho*Wo*Co*KS^2*C each) / their summed duration.  `traffic` is NOT measured here: it is the
+    per-launch HBM-side byte count from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads)."""
     from avvad import _lib as L
     lib = L.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -91,10 +96,10 @@ def roofline_probe(torch, n_frames, reps=5):
         tot_ms += ms
         n_launch += 1
     ach = tot_flop / tot_ms / 1e9
-    return {"bound": "mfma", "kernel": "igemm::kernel<128,128,Im2colFwd,ColPlain<4>,EpiStore> (trunk conv forward, Cout>=128)",
+    return {"bound": "mfma", "kernel": "igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,EpiStore> (trunk conv forward, Cout>=128)",
             "launches_per_step": n_launch, "avg_launch_us": round(1e3 * tot_ms / n_launch, 2),
             "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-            "traffic": None,
+            "traffic": TRAFFIC_PER_LAUNCH_BYTES, "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC, profiles/r01_pmc_*_size_per_kernel.csv)",
             "per_shape": [{"C": a, "Co": b, "HW": c_, "k": d_, "s": e, "us": round(1e3 * f, 1), "TFLOPs": round(g, 1)}
                           for (a, b, c_, d_, e, f, g) in per]}
 
@@ -112,7 +117,7 @@ def cpu_baseline(torch, n_seq=32):
     wave, video, target, lengths = make_inputs(torch, n_seq, 99, None)
     lens = lengths.tolist()
     times = []
-    for it in range(6):
+    for it in range(11):
         t0 = time.perf_counter()
         y = models.av_net(sd, wave, video, lens, 2, training=True, wavenet_cfg=W0)
         loss = head.batch_loss(y, target, lens, 1e-8)
@@ -124,7 +129,7 @@ def cpu_baseline(torch, n_seq=32):
     t = sorted(times[1:])[len(times[1:]) // 2]
     return {"value": round(n_seq * T_FRAMES / t, 1), "unit": "frame-pairs/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "oracle AV model (WaveNet W0 + ResNet-18 + 2xLSTM1024 + FC), forward+loss+backward, %d seq x %d frames, "
-                      "median of 5 after 1 warm-up, %.2f s each" % (n_seq, T_FRAMES, t)}
+                      "median of 10 after 1 warm-up, %.2f s each" % (n_seq, T_FRAMES, t)}
 
 
 def parity_probe(torch):
