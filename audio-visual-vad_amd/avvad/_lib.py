@@ -65,6 +65,10 @@ class McbDesc(C.Structure):
                 ("training", C.c_int), ("momentum", C.c_float), ("save_for_backward", C.c_int)]
 
 
+class StftDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("L", C.c_long), ("n_fft", C.c_int), ("hop", C.c_int), ("T", C.c_int), ("eps", C.c_float)]
+
+
 class LstmDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("In", C.c_int), ("H", C.c_int), ("lengths", FP),
                 ("save_for_backward", C.c_int)]
@@ -93,6 +97,8 @@ SIGNATURES = {
     "avvad_mcb_workspace": (C.c_size_t, [C.POINTER(McbDesc)]),
     "avvad_mcb_fusion_fwd": (C.c_int, [FP] * 11 + [C.POINTER(McbDesc), FP, C.c_size_t, FP]),
     "avvad_mcb_fusion_bwd": (C.c_int, [FP] * 12 + [C.POINTER(McbDesc), FP, C.c_size_t, FP]),
+    "avvad_stft_workspace": (C.c_size_t, [C.POINTER(StftDesc)]),
+    "avvad_stft": (C.c_int, [FP, FP, C.POINTER(StftDesc), C.c_int, FP, C.c_size_t, FP]),
     "avvad_bce_masked": (C.c_int, [FP, FP, FP, FP, FP, C.c_int, C.c_int, C.c_int, C.c_float, FP]),
     "avvad_adam_step": (C.c_int, [FP, FP, FP, FP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, FP]),
     "avvad_copy_cols": (C.c_int, [FP, FP, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, FP]),

@@ -405,3 +405,30 @@ class TransposeLast2Fn(torch.autograd.Function):
         dx = torch.empty(B, Cc, T, dtype=torch.float32, device=dy.device)
         L.check(L.lib().avvad_transpose_last2(L.ptr(dy), L.ptr(dx), B, T, Cc, _stream()), "avvad_transpose_last2")
         return dx
+
+
+# --------------------------------------------------------------------------- STFT front-end (no gradient)
+def n_frames(L, n_fft, hop, pad_at_end=True, fs=16e3):
+    """frame count of stft_pytorch(center=False): one hop of zeros is appended when the utterance is not a whole
+    number of hops (packages/processing/stft.py:134-139)."""
+    import math
+    wlen_sec, hop_percent = n_fft / fs, hop / n_fft
+    if pad_at_end:
+        v = L / fs / wlen_sec / hop_percent
+        if math.ceil(v) != int(v):
+            L = L + hop
+    return (L - n_fft) // hop + 1
+
+
+def stft(wave, n_fft=1024, hop=256, mode=0, eps=1e-8, pad_at_end=True, fs=16e3):
+    """wave (B,L) or (L,) on the GPU.  mode 0: log-power (B,T,F); 1: power (B,T,F); 2: legacy real view (F,T,2)."""
+    w = _dev(wave, "wave")
+    w2 = w.view(1, -1) if w.dim() == 1 else w
+    B, Ls = w2.shape
+    T = n_frames(Ls, n_fft, hop, pad_at_end, fs)
+    F = n_fft // 2 + 1
+    d = L.StftDesc(B, Ls, n_fft, hop, T, float(eps))
+    ws = _ws(L.lib().avvad_stft_workspace(C.byref(d)), w.device)
+    out = torch.empty((F, T, 2) if mode == 2 else (B, T, F), dtype=torch.float32, device=w.device)
+    L.check(L.lib().avvad_stft(L.ptr(w2), L.ptr(out), C.byref(d), mode, L.ptr(ws), ws.numel() * 4, _stream()), "avvad_stft")
+    return out

@@ -15,6 +15,9 @@ def stft_pytorch(x, fs=16e3, wlen_sec=50e-3, win='hann', hop_percent=0.25, cente
         raise ValueError("wlen_sample of STFT is not an integer.")
     nfft = int(wlen_sec * fs)
     hopsamp = int(hop_percent * nfft)
+    if x.is_cuda and not center and isinstance(win, str) and win == 'hann' and nfft % 32 == 0:
+        from avvad import ops                      # GPU: framing + Hann + DFT as one MFMA GEMM (csrc/stft.hip)
+        return ops.stft(x, nfft, hopsamp, mode=2, pad_at_end=pad_at_end, fs=fs)
     x_ = x
     if pad_at_end:
         n_hops = len(x) / fs / wlen_sec / hop_percent
@@ -29,6 +32,14 @@ def stft_pytorch(x, fs=16e3, wlen_sec=50e-3, win='hann', hop_percent=0.25, cente
     S = torch.stft(input=x_, n_fft=nfft, hop_length=hopsamp, win_length=None, window=window, center=center,
                    pad_mode=pad_mode, return_complex=True)
     return torch.view_as_real(S)
+
+
+def log_power_spectrogram(x, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, eps=1e-8, pad_at_end=True):
+    """Fused form of the callers' stft_pytorch -> re^2+im^2 -> log(.+eps) -> transpose chain
+    (scripts/evaluate_audio_net.py:131-163): x (B,L) or (L,) on the GPU -> (B,T,513) log-power features."""
+    from avvad import ops
+    nfft = int(wlen_sec * fs)
+    return ops.stft(x, nfft, int(hop_percent * nfft), mode=0, eps=eps, pad_at_end=pad_at_end, fs=fs)
 
 
 def log_power(S, eps=1e-8):

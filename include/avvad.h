@@ -226,6 +226,24 @@ int avvad_mcb_fusion_bwd(const float* audio, const float* video, const int64_t* 
                          const avvad_mcb_desc* d, void* ws, size_t ws_bytes, avvad_stream_t s);
 
 /* ------------------------------------------------------------------------
+ * STFT log-power front-end: framing + periodic Hann + real DFT (one MFMA GEMM) + |X|^2 (+ log)
+ * Replaces: stft_pytorch packages/processing/stft.py:102-151 (center=False; the optional one-hop zero pad at
+ *   the end is implied by T: frames may run at most one hop past L and read zeros there) and the callers'
+ *   power / log, scripts/evaluate_audio_net.py:141-148, packages/data_handling.py:454-457.
+ * wave [B][L].  mode 0: out [B][T][F] = log(|X|^2 + eps); mode 1: out = |X|^2; mode 2 (B == 1): out [F][T][2] =
+ * (re, im), the legacy torch.stft real view the reference's callers index.  F = n_fft/2 + 1, n_fft % 32 == 0.
+ * ---------------------------------------------------------------------- */
+typedef struct {
+  int B;
+  long L;
+  int n_fft, hop, T;
+  float eps;
+} avvad_stft_desc;
+size_t avvad_stft_workspace(const avvad_stft_desc* d);
+int avvad_stft(const float* wave, float* out, const avvad_stft_desc* d, int mode, void* ws, size_t ws_bytes,
+               avvad_stream_t s);
+
+/* ------------------------------------------------------------------------
  * Masked BCE-with-eps loss, summed over sequences
  * Replaces: binary_cross_entropy packages/models/utils.py:108-113 and its caller
  *   loop scripts/train_AV_net.py:298-301  (per-sequence mean over valid frames

@@ -455,3 +455,21 @@ def test_training_steps_match_cpu_adam():
     # the in-place path really was used: .grad tensors are views of the flat buffer
     p0 = next(m.parameters())
     assert p0.grad.data_ptr() >= opt.flat_grad.data_ptr() and p0.grad.data_ptr() < opt.flat_grad.data_ptr() + 4 * opt.flat_grad.numel()
+
+
+@pytest.mark.parametrize("L", [16000, 16001, 4096 + 768])
+def test_stft_frontend_gpu(L):
+    """GPU STFT (framing + Hann + DFT as one MFMA GEMM) vs the oracle restatement of stft_pytorch (torch.stft on the
+    CPU) incl. the pad / no-pad branch, and the fused log-power features of a ragged-free batch."""
+    from oracle import frontend
+    from packages.processing.stft import log_power_spectrogram, stft_pytorch
+    x = stategen.rand(90, L, scale=0.3)
+    x = x / x.abs().max()
+    ref = frontend.stft(x, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, center=False, pad_at_end=True)
+    S = stft_pytorch(x.to(DEV), fs=16e3, wlen_sec=64e-3, win='hann', hop_percent=0.25, center=False, pad_at_end=True)
+    assert tuple(S.shape) == tuple(ref.shape)
+    _report("stft re/im L=%d" % L, S, ref, 5e-4)
+    xb = torch.stack([x, x.flip(0) * 0.5])
+    lp = log_power_spectrogram(xb.to(DEV))
+    pw_ref = torch.stack([(frontend.stft(r, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, center=False) ** 2).sum(-1).t() for r in xb])
+    _report("stft power L=%d" % L, torch.exp(lp) - 1e-8, pw_ref, 2e-3, 1e-4)
