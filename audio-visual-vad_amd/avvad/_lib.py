@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libavvad_hip.so")
+LIB_PATH = os.environ.get("AVVAD_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libavvad_hip.so")
 
 TRUNK_NCONV = 20
 _ERR = {-1: "AVVAD_EINVAL (bad descriptor / unsupported shape)", -2: "AVVAD_EWORKSPACE (workspace too small)",

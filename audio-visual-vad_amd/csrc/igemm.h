@@ -234,12 +234,6 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
       const int cur = DB ? ((kt - kt0) & 1) : 0;
       float* As = smem + cur * TILE;
       float* Bs = As + BK * SA::LD;
-      if (DB && kt + 1 < kt1) {  // stage tile kt+1 into the other buffer (its readers passed the last barrier)
-        float* An = smem + (cur ^ 1) * TILE;
-        SA::to_lds(An, t, sa);
-        SB::to_lds(An + BK * SA::LD, t, sb);
-        if (kt + 2 < kt1) gload(kt + 2);  // in flight during the MFMAs below
-      }
       const float* ap = As + lh * SA::LD + wm * (BM / 2) + li;
       const float* bp = Bs + lh * SB::LD + wn * (BN / WGN) + li;
       float a[2][TM], b[2][TN];
@@ -249,12 +243,25 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
       for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
 #pragma unroll
       for (int ks = 0; ks < BK / 2; ++ks) {
+        if (DB && ks == BK / 4 && kt + 1 < kt1) {
+          // MID-tile staging (double-buffered LDS): the wait for tile kt+1's global loads, its LDS writes (other
+          // buffer: its readers passed the last barrier) and the issue of tile kt+2's loads sit between the two
+          // halves of this tile's MFMAs instead of right behind the barrier, where every wave of both co-resident
+          // workgroups would do them at the same time with the matrix pipe idle.
+          float* An = smem + (cur ^ 1) * TILE;
+          SA::to_lds(An, t, sa);
+          SB::to_lds(An + BK * SA::LD, t, sb);
+          if (kt + 2 < kt1) gload(kt + 2);
+        }
         if (ks + 1 < BK / 2) {  // fragments of the next k-step are in flight under this step's MFMAs
 #pragma unroll
           for (int i = 0; i < TM; ++i) a[(ks + 1) & 1][i] = ap[(ks + 1) * 2 * SA::LD + i * 32];
 #pragma unroll
           for (int j = 0; j < TN; ++j) b[(ks + 1) & 1][j] = bp[(ks + 1) * 2 * SB::LD + j * 32];
         }
+        // pin the prefetch ABOVE this step's MFMAs: left alone, hipcc sinks the ds_reads below them (operand
+        // registers get reused) and every k-step then eats the LDS latency in front of its MFMAs
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
