@@ -203,3 +203,24 @@ def test_dp_bucket_reducer_gloo_world2(tmp_path):
     assert float(flat.abs().sum()) > 0
     with pytest.raises(ValueError):
         avd.shard_batch([torch.zeros(5, 2)], 0, 2)
+
+
+def test_direct_gradient_sinks_notify_the_reducer():
+    """Backward kernels accumulate straight into the flat gradient buffer and bypass autograd's AccumulateGrad
+    hooks; the bucket reducer must still learn about every parameter (avvad.ops.GRAD_SINKS)."""
+    from avvad import dist as avd
+    from avvad import ops
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7))]
+    flat, offsets = avd.flat_views(ps)
+    seen = []
+    ops.GRAD_SINKS.append(seen.append)
+    try:
+        tg = [ops._grad_target(p, True) for p in ps]
+        assert all(direct for _, direct in tg) and tg[0][0].data_ptr() == flat.data_ptr()
+        assert ops._finish_grads(ps, tg) == [None, None] and [id(p) for p in seen] == [id(p) for p in ps]
+        fresh = torch.nn.Parameter(torch.randn(2))          # no .grad yet -> a zero temporary goes back to autograd
+        g, direct = ops._grad_target(fresh, True)
+        assert not direct and float(g.abs().sum()) == 0.0
+        assert ops._grad_target(ps[0], False) == (None, False)
+    finally:
+        ops.GRAD_SINKS.remove(seen.append) if seen.append in ops.GRAD_SINKS else ops.GRAD_SINKS.clear()

@@ -473,3 +473,80 @@ def test_stft_frontend_gpu(L):
     lp = log_power_spectrogram(xb.to(DEV))
     pw_ref = torch.stack([(frontend.stft(r, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, center=False) ** 2).sum(-1).t() for r in xb])
     _report("stft power L=%d" % L, torch.exp(lp) - 1e-8, pw_ref, 2e-3, 1e-4)
+
+
+# ------------------------------------------------------------------------------------------ BASELINE-size properties
+def _max_rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def test_full_size_c2_wavenet_batch_split():
+    """BASELINE configs[1] shape: 256 one-second chunks (256,1,16000) through the W0 encoder.  No oracle run at this
+    size (94 MB of activations per chunk on the CPU): the size-independent property is that sequences are
+    independent -- the batch of 256 equals 4 runs of 64 (catches 32-bit index overflow, tile tails, grid caps)."""
+    from packages.models.wavenet_autoencoder import wavenet_autoencoder
+    cfg = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in range(10)] * 2, en_residual_channel=32,
+               en_dilation_channel=32, en_bottleneck_width=256, en_pool_kernel_size=60, use_bias=True)
+    torch.manual_seed(0)
+    m = wavenet_autoencoder(**cfg).to(DEV)
+    x = torch.rand(256, 1, 16000, device=DEV) * 2 - 1
+    with torch.no_grad():
+        full = m(x)
+        parts = torch.cat([m(x[i:i + 64]) for i in range(0, 256, 64)])
+    assert full.shape == (256, 256, 60) and torch.isfinite(full).all()
+    assert _max_rel(full, parts) == 0.0          # the forward encoder is deterministic and batch-independent
+
+
+def test_full_size_c3_trunk_batch_split_and_scale():
+    """BASELINE configs[2] shape: 512 lip crops.  Eval-mode trunk: frames are independent (512 == 2 x 256 up to the
+    float-atomic order of split tiles) and the stem is linear before the first ReLU, so scaling every conv weight of
+    a BN-free path is not available -- instead check positive homogeneity of the ReLU network in eval mode with the
+    BN shifts zeroed: f(a*x) == a*f(x)."""
+    from packages.models.Video_Net import DeepVAD_video
+    from avvad import nn as avnn
+    torch.manual_seed(0)
+    m = DeepVAD_video(1, 8, 1).to(DEV).eval()
+    x = torch.randn(512, 67, 67, device=DEV)
+    with torch.no_grad():
+        full = avnn.trunk_forward(m.features, x, False)
+        parts = torch.cat([avnn.trunk_forward(m.features, x[:256], False), avnn.trunk_forward(m.features, x[256:], False)])
+        assert full.shape == (512, 512) and torch.isfinite(full).all()
+        assert _max_rel(full, parts) < 1e-5
+        # running_mean = 0, beta = 0 (fresh BatchNorm) -> the eval network is conv/scale/ReLU/max/mean only
+        half = avnn.trunk_forward(m.features, 0.5 * x, False)
+        assert _max_rel(half, 0.5 * full) < 1e-5
+
+
+def test_full_size_c4_dp_shard_gradient_sum():
+    """BASELINE configs[3]/[4] per-GPU shard (64 sequences x 16 frames, W0 encoder, 2xLSTM1024): the data-parallel
+    property on ONE GPU.  With BatchNorm in eval mode the summed-over-sequences loss makes
+    grad(full batch) == grad(shard 0) + grad(shard 1) -- exactly what the SUM all-reduce relies on."""
+    from packages.models.AV_Net import DeepVAD_AV
+    from packages.models.utils import batch_binary_cross_entropy
+    sys_path_bench = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(sys_path_bench, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    torch.manual_seed(0)
+    m = DeepVAD_AV(2, 1024, 1, wavenet_params=bench.W0).to(DEV).eval()
+    wave, video, target, lengths = bench.make_inputs(torch, 64, 1234, torch.device(DEV))
+    lengths = lengths.clone()
+    lengths[::3] = 11                                   # ragged
+    params = [p for n, p in m.named_parameters() if not n.startswith("bn.")]
+
+    def grads(sl):
+        for p in params:
+            p.grad = None
+        y = m(wave[sl], video[sl], lengths[sl])
+        loss = batch_binary_cross_entropy(y, target[sl], lengths[sl], 1e-8)
+        loss.backward()
+        return float(loss.detach()), [p.grad.clone() for p in params]
+
+    lf, gf = grads(slice(0, 64))
+    l0, g0 = grads(slice(0, 32))
+    l1, g1 = grads(slice(32, 64))
+    assert abs(lf - (l0 + l1)) < 1e-3 * abs(lf)
+    worst = max(float(((a + b) - f).norm() / f.norm().clamp_min(1e-30)) for f, a, b in zip(gf, g0, g1))
+    print("DP shard-sum property: loss %.4f = %.4f + %.4f, worst relL2 over %d tensors %.2e" % (lf, l0, l1, len(gf), worst))
+    assert worst < 5e-3       # float-atomic split-K order differs between the three runs; a wrong shard sum would be O(1)
