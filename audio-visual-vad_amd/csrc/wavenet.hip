@@ -466,6 +466,9 @@ __global__ void __launch_bounds__(256)
 }
 
 
+constexpr int WG_SLAB = 3 * 1024 + 64;   // per-workgroup partial sums of wn_block_wgrad_mfma
+constexpr int WG_MAXBLK = 512;
+
 // ------------------------------------------------------------------ fused MFMA weight/bias gradients of a residual block (R = D = 32, fw = 2)
 //   dW_dil[d][c][k] += sum_t dz[d][t] relu(s_in[c][t + k*dil])      db_dil[d]   += sum_t dz[d][t]
 //   dW_dense[r][d]  += sum_t dS[r][t] relu(z[d][t])                 db_dense[r] += sum_t dS[r][t]
@@ -476,8 +479,7 @@ __global__ void __launch_bounds__(256)
 // reductions per layer.
 __global__ void __launch_bounds__(256)
     wn_block_wgrad_mfma(const float* __restrict__ dS, const float* __restrict__ Z, const float* __restrict__ DZ,
-                        const float* __restrict__ s_in, float* __restrict__ dW_dil, float* __restrict__ db_dil,
-                        float* __restrict__ dW_dense, float* __restrict__ db_dense, int B, int Lin, int dil) {
+                        const float* __restrict__ s_in, float* __restrict__ slab, int B, int Lin, int dil) {
   __shared__ float tile[4][32 * 33];
   __shared__ float red[3 * 1024 + 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -555,16 +557,24 @@ __global__ void __launch_bounds__(256)
   atomicAdd(&red[3072 + li], bs_dz);
   atomicAdd(&red[3104 + li], bs_ds);
   __syncthreads();
-  for (int i = threadIdx.x; i < 1024; i += 256) {
-    const int row = i >> 5, col = i & 31;
-    atomicAdd(dW_dil + (row * 32 + col) * 2 + 0, red[i]);
-    atomicAdd(dW_dil + (row * 32 + col) * 2 + 1, red[1024 + i]);
-    atomicAdd(dW_dense + i, red[2048 + i]);
-  }
-  if (threadIdx.x < 32) {
-    if (db_dil) atomicAdd(db_dil + threadIdx.x, red[3072 + threadIdx.x]);
-    if (db_dense) atomicAdd(db_dense + threadIdx.x, red[3104 + threadIdx.x]);
-  }
+  // one slab of 3136 partial sums per workgroup (plain stores); wn_wgrad_reduce adds the slabs in a fixed order.
+  // (640 workgroups doing float atomics onto the SAME 3136 addresses ran at the contended-atomic rate: 90 us.)
+  float* out = slab + (long)blockIdx.x * WG_SLAB;
+  for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
+}
+
+// dW_dil[d][c][k] += sum_blocks slab[k*1024 + d*32 + c]; dW_dense[r][d] += slab[2048 + r*32 + d]; biases likewise
+__global__ void __launch_bounds__(256)
+    wn_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restrict__ dW_dil, float* __restrict__ db_dil,
+                    float* __restrict__ dW_dense, float* __restrict__ db_dense) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= WG_SLAB) return;
+  float s = 0.f;
+  for (int b = blockIdx.y; b < nslab; b += gridDim.y) s += slab[(long)b * WG_SLAB + i];   // gridDim.y partial sums
+  if (i < 2048) atomicAdd(dW_dil + (i & 1023) * 2 + (i >> 10), s);
+  else if (i < 3072) atomicAdd(dW_dense + i - 2048, s);
+  else if (i < 3104) { if (db_dil) atomicAdd(db_dil + i - 3072, s); }
+  else if (db_dense) atomicAdd(db_dense + i - 3104, s);
 }
 
 // ------------------------------------------------------------------ plan / workspace
@@ -574,6 +584,7 @@ struct Plan {
   size_t s[66];     // offsets of s_i (floats); without save_for_backward only 2 ping-pong buffers
   size_t z, dz, ga, gb, dzt;
   size_t zs[66];    // per-layer pre-ReLU dilation outputs kept for backward (MFMA shape); else 0
+  size_t slab;      // weight-gradient partial slabs
   size_t total;
 };
 static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
@@ -593,6 +604,7 @@ static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
     p->z = take(big); p->dz = take(big); p->ga = take(big); p->gb = take(big);
     p->dzt = take(B * d->Bn * p->L[p->n]);
     for (int i = 0; i < p->n; ++i) p->zs[i] = (d->R == 32 && d->D == 32 && d->fw == 2) ? take(B * d->D * p->L[i + 1]) : 0;
+    p->slab = take((size_t)WG_MAXBLK * WG_SLAB);
   } else {
     for (int i = 0; i < p->n; ++i) p->zs[i] = 0;
     const size_t a = take(B * d->R * p->L[0]), b2 = take(B * d->R * p->L[0]);
@@ -739,12 +751,13 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
       if (blocks > 768) blocks = 768;
       hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], DZ, B, Lo);
       if (g->dil_w_h[i] && g->dense_w_h[i]) {
-        long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave: the final reduction is amortised
-        if (wb > 768) wb = 768;
+        long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave
+        if (wb > WG_MAXBLK) wb = WG_MAXBLK;
         if (wb < 1) wb = 1;
-        hipLaunchKernelGGL(wn_block_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, DZ, si, g->dil_w_h[i],
+        hipLaunchKernelGGL(wn_block_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, DZ, si, ws + p.slab, B, Li, dil);
+        hipLaunchKernelGGL(wn_wgrad_reduce, dim3(cdiv(WG_SLAB, 256), 32), dim3(256), 0, s, ws + p.slab, (int)wb, g->dil_w_h[i],
                            d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
-                           d->use_bias ? g->dense_b_h[i] : (float*)nullptr, B, Li, dil);
+                           d->use_bias ? g->dense_b_h[i] : (float*)nullptr);
       }
       blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
       if (blocks > 512) blocks = 512;
