@@ -405,6 +405,11 @@ __global__ void __launch_bounds__(256)
   const long ntiles = (long)B * tiles_per_seq;
   const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  // the bottleneck weights (Bn x 32) are copied coalesced into padded LDS once per workgroup: the per-lane fragment
+  // pattern is a 128-byte-strided gather (32 cache lines per load instruction) that made this kernel TA-bound
+  extern __shared__ float wl[];
+  for (int i = threadIdx.x; i < Bn * 32; i += 256) wl[(i >> 5) * 33 + (i & 31)] = wb[i];
+  __syncthreads();
   for (long tile = wave0; tile < ntiles; tile += nwaves) {
     const int b = (int)(tile / tiles_per_seq);
     const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
@@ -438,8 +443,8 @@ __global__ void __launch_bounds__(256)
       float wz[16], wt[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) {
-        wz[k] = wb[(long)(nb + li) * 32 + 2 * k + lh];            // A[i = bn][k = c] for z
-        wt[k] = wb[(long)(nb + mfma32_row(k, lh)) * 32 + li];      // A[i = c][k = bn] for dS
+        wz[k] = wl[(nb + li) * 33 + 2 * k + lh];                  // A[i = bn][k = c] for z
+        wt[k] = wl[(nb + mfma32_row(k, lh)) * 33 + li];            // A[i = c][k = bn] for dS
       }
       f32x16 accZ;
 #pragma unroll
@@ -719,11 +724,11 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
   float* GB = ws + p.gb;  // d s_i
   // ---- tail: dz_t = relu'(z) * pooled-grad ; d s_N = Wb^T dz_t
   float* DZT = ws + p.dzt;
-  const bool tail_mfma = (R == 32 && Bn % 32 == 0);
+  const bool tail_mfma = (R == 32 && Bn % 32 == 0 && Bn <= 1024);
   if (tail_mfma) {
     long blocks = ((long)B * cdiv(Lv, 32) + 3) / 4;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(tail_bwd_mfma, dim3((int)blocks), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,
+    hipLaunchKernelGGL(tail_bwd_mfma, dim3((int)blocks), dim3(256), (size_t)Bn * 33 * sizeof(float), s, ws + p.s[p.n], prm->bott_w,
                        d->use_bias ? prm->bott_b : (const float*)nullptr, dout, DZT, GA, B, Bn, Lv, d->P);
   } else {
     hipLaunchKernelGGL(tail_bwd_dz_generic, dim3(grid1((long)B * Bn * Lv)), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,

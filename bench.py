@@ -226,7 +226,7 @@ def main():
                           "per_gpu_frame_pairs": N_SEQ * T_FRAMES, "global_frame_pairs": fp_per_step, "sequences_per_gpu": N_SEQ,
                           "frames_per_sequence": T_FRAMES, "samples_per_sequence": T_FRAMES * HOP + RF - 1,
                           "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)}}
-        if not args.no_extras:
+        if not args.no_extras and world == 1:     # roofline / parity / CPU baseline: rank 0 at N=1 only
             out["roofline"] = roofline_probe(torch, N_SEQ * T_FRAMES)
             log("roofline probe done")
             out["cpu_ref_max_abs_delta"] = parity_probe(torch)
