@@ -226,13 +226,14 @@ def main():
                           "per_gpu_frame_pairs": N_SEQ * T_FRAMES, "global_frame_pairs": fp_per_step, "sequences_per_gpu": N_SEQ,
                           "frames_per_sequence": T_FRAMES, "samples_per_sequence": T_FRAMES * HOP + RF - 1,
                           "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)}}
-        if not args.no_extras and world == 1:     # roofline / parity / CPU baseline: rank 0 at N=1 only
+        if not args.no_extras:
             out["roofline"] = roofline_probe(torch, N_SEQ * T_FRAMES)
             log("roofline probe done")
-            out["cpu_ref_max_abs_delta"] = parity_probe(torch)
-            log("parity probe done")
-            out["cpu_baseline"] = cpu_baseline(torch)
-            log("cpu baseline done")
+            if world == 1:     # CPU baseline and CPU-reference delta: rank 0 at N=1 only
+                out["cpu_ref_max_abs_delta"] = parity_probe(torch)
+                log("parity probe done")
+                out["cpu_baseline"] = cpu_baseline(torch)
+                log("cpu baseline done")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
