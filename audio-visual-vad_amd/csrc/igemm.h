@@ -154,18 +154,19 @@ struct Stage {
   }
 };
 
-// Work decomposition: "stream-K".  The launch creates G persistent workgroups (= the number that is resident
-// at once: 256 CUs x blocks/CU), the iteration space is ntiles x ktiles BK-deep MAC iterations, and worker g
-// owns the contiguous range [it0, it1).  When the tile count fills the machine evenly the ranges are aligned to
-// whole tiles (plain data-parallel tiling, plain stores); otherwise they are equal shares, a tile may be split
-// between workers and split pieces are added with float atomics onto a pre-zeroed (or accumulating) output.
-// That removes the tile-quantisation loss of e.g. 648 or 288 tiles on 512 resident slots (37 % / 44 % idle).
+// Work decomposition: data-parallel rounds + one "stream-K" round.  The launch creates G persistent workgroups
+// (= the number resident at once: 256 CUs x workgroups/CU).  Worker g first takes whole tiles g, g+G, ... for
+// `full_rounds` rounds (plain stores, all workers walk K in step -> weight panels are shared in L2); the
+// remaining rem_tiles < G tiles are then treated as ONE pool of rem_tiles x ktiles BK-deep iterations cut into G
+// equal contiguous shares: a tile may be split between workers, and split pieces are added with float atomics onto
+// a pre-zeroed (or accumulating) output.  That removes the tile-quantisation loss of e.g. 648 or 288 tiles on 512
+// resident slots (37 % / 44 % idle) while only the last round pays the ~1.3 TB/s float-atomic rate.
 // NTH = 256: 4 waves as 2x2, each (BM/2)x(BN/2);  NTH = 512: 8 waves as 2x4, each (BM/2)x(BN/4) -- half the
 // accumulators and staging registers per wave, so twice the waves per SIMD fit next to the same LDS tile.
 template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi>
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 128) ? 2 : 3))
     kernel(const AOp A, const BOp B, const Epi E, const int M, const int N, const int K, const int ktiles,
-           const long iters, const int tile_aligned) {
+           const int full_rounds, const int rem_tiles) {
   typedef Stage<AOp, BM, NTH> SA;
   typedef Stage<BOp, BN, NTH> SB;
   constexpr int WGN = NTH / 128;                  // waves along N (2 or 4); 2 along M
@@ -181,21 +182,28 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
 
   const long G = gridDim.x;
   const long g = xcd_remap(blockIdx.x, gridDim.x);
-  long it, it_end;
-  if (tile_aligned) {
-    const long ntiles = iters / ktiles;
-    it = (g * ntiles / G) * ktiles;
-    it_end = ((g + 1) * ntiles / G) * ktiles;
-  } else {
-    it = g * iters / G;
-    it_end = (g + 1) * iters / G;
-  }
+  const long rem_iters = (long)rem_tiles * ktiles;
+  long it = g * rem_iters / G;
+  const long it_end = (g + 1) * rem_iters / G;
+  const long ntiles_all = (long)((M + BM - 1) / BM) * ntn;
+  int round = 0;
 
-  while (it < it_end) {
-    const int tile = (int)(it / ktiles);
-    const int kt0 = (int)(it - (long)tile * ktiles);
-    const int kt1 = (int)min((long)ktiles, kt0 + (it_end - it));
-    it += kt1 - kt0;
+  for (;;) {
+    int tile, kt0, kt1;
+    if (round < full_rounds) {                       // data-parallel rounds: whole tiles
+      const long tl = (long)round * G + g;
+      ++round;
+      if (tl >= ntiles_all) continue;                // last, partially filled round
+      tile = (int)tl; kt0 = 0; kt1 = ktiles;
+    } else if (it < it_end) {                        // stream-K round over the remainder tiles
+      const long tr = it / ktiles;
+      tile = (int)((long)full_rounds * G + tr);
+      kt0 = (int)(it - tr * ktiles);
+      kt1 = (int)min((long)ktiles, kt0 + (it_end - it));
+      it += kt1 - kt0;
+    } else {
+      break;
+    }
     const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
 
     typename AOp::Ctx actx[SA::NCTX];
@@ -320,13 +328,18 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   else if (variant == 1 || !BIG) per_cu = BIG ? 3 : (BM * BN >= 128 * 64 ? 4 : 6);
   else per_cu = 2;
   long G = (long)NUM_CU * per_cu;
-  const long rounds = (ntiles + G - 1) / G;
   const char* nsk = getenv("AVVAD_NO_STREAMK");   // debugging aid: "all", or the epilogue mode digit to restrict
   const bool no_sk = nsk && (nsk[0] == 'a' || nsk[0] - '0' == e.mode);
-  const bool aligned = no_sk || (ntiles >= G && (double)ntiles / (double)(rounds * G) >= 0.9);
-  if (!aligned) {
-    const long cap = iters / 4 > 0 ? iters / 4 : 1;  // >= 4 iterations per worker: prologue/epilogue amortised
-    if (G > cap) G = cap;
+  long full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
+  if (no_sk || rem * 10 >= G * 9) {   // (nearly) full last round: keep it data-parallel
+    if (rem > 0) ++full_rounds;
+    rem = 0;
+  }
+  if (rem > 0) {
+    if (full_rounds == 0) {           // fewer tiles than workers: >= 4 iterations per worker amortise prologue/epilogue
+      const long cap = iters / 4 > 0 ? iters / 4 : 1;
+      if (G > cap) G = cap;
+    }
     // (AVVAD_SKIP_ZERO: timing aid for bench.py's roofline probe, which wants the GEMM kernel's own duration --
     // the zero-fill is a separate kernel with its own line in the rocprof summary; results are garbage with it set)
     if (e.mode == 0 && !getenv("AVVAD_SKIP_ZERO")) {  // split pieces are atomically added: the output must start at zero
@@ -335,15 +348,14 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
                          e.ldc, e.cs);
     }
   }
+  const int fr = (int)full_rounds, rt = (int)rem;
   if (variant == 0)
-    hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, iters,
-                       aligned ? 1 : 0);
+    hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt);
   else if (variant == 1 || !BIG)
-    hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, iters,
-                       aligned ? 1 : 0);
+    hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt);
   else
     hipLaunchKernelGGL((kernel<BM, BN, true, (BIG ? 512 : 256), AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K,
-                       ktiles, iters, aligned ? 1 : 0);
+                       ktiles, fr, rt);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }
