@@ -23,6 +23,18 @@ struct Geom {
   int N, H, W, C, Ho, Wo, Co, KS, stride, pad;
 };
 
+// exact unsigned division by a runtime constant: q = mulhi(k, magic), magic = floor(2^32/d) + 1, valid for
+// k * d < 2^32 (checked on the host) -- one v_mul_hi_u32 instead of the ~30-instruction software divide that the
+// pixel decomposition of every gathered element would otherwise cost
+static inline unsigned div_magic(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull / d) + 1ull); }   // 0: divide by 1
+__device__ __forceinline__ int fast_div(int k, unsigned magic) { return magic ? (int)__umulhi((unsigned)k, magic) : k; }
+
+// magic numbers of the divisors that appear in the per-K-tile tap decomposition
+struct TapDiv {
+  unsigned mg_T, mg_KS;
+};
+static inline TapDiv tap_div(int T, int KS) { return TapDiv{div_magic((unsigned)T), div_magic((unsigned)KS)}; }
+
 // ---- forward A: rows = output pixels, K = (kh,kw,c), c contiguous (16-byte loads)
 struct Im2colFwd {
   static constexpr bool KCONTIG = true;
@@ -31,6 +43,7 @@ struct Im2colFwd {
   const float* x;
   Geom g;
   int M;
+  TapDiv td;
   __device__ __forceinline__ Ctx prep(int m) const {
     Ctx c;
     if (m >= M) { c.base = -1; c.hi0 = c.wi0 = 0; return c; }
@@ -44,9 +57,9 @@ struct Im2colFwd {
   }
   __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
     const int T = g.KS * g.KS, q = k0 >> 5;  // wave-uniform (k0 % 32 == 0, C % 32 == 0)
-    const int cc = q / T, tap = q - cc * T;
+    const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
     const int c0 = cc * 32 + kin;
-    const int kh = tap / g.KS, kw = tap - kh * g.KS;
+    const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
     const int hi = c.hi0 + kh, wi = c.wi0 + kw;
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (c.base >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
@@ -64,6 +77,7 @@ struct Im2colDgrad {
   const float* dy;
   Geom g;
   int M;
+  TapDiv td;
   __device__ __forceinline__ Ctx prep(int m) const {
     Ctx c;
     if (m >= M) { c.base = -1; c.hp = c.wp = 0; return c; }
@@ -77,9 +91,9 @@ struct Im2colDgrad {
   }
   __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
     const int T = g.KS * g.KS, q = k0 >> 5;
-    const int cc = q / T, tap = q - cc * T;
+    const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
     const int c0 = cc * 32 + kin;
-    const int kh = tap / g.KS, kw = tap - kh * g.KS;
+    const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
     const int th = c.hp - kh, tw = c.wp - kw;
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (c.base < 0 || th < 0 || tw < 0) return;
@@ -184,12 +198,13 @@ struct ColTapRows {
   const float* p;
   long ld;
   int X, K, C, T;
+  unsigned mg_T;
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
   __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (k < K && x < X) {
-      const int q = k >> 5, cc = q / T, tap = q - cc * T;
+      const int q = k >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;
       const float4 t = *reinterpret_cast<const float4*>(p + (long)(tap * C + cc * 32 + (k & 31)) * ld + x);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     }
@@ -203,8 +218,9 @@ struct EpiWgrad {
   int mode;           // 2
   int cs;
   int Cch, T;
+  unsigned mg_T;
   __device__ __forceinline__ float* at(int m, int n) const {
-    const int q = m >> 5, cc = q / T, tap = q - cc * T;
+    const int q = m >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;
     return C + (long)(tap * Cch + cc * 32 + (m & 31)) * ldc + n;
   }
   __device__ __forceinline__ void store(int m, int n, float v) const { atomicAdd(at(m, n), v); }
@@ -220,6 +236,7 @@ struct WgradX {
   const float* x;
   Geom g;
   int M, K;
+  unsigned mg_hw, mg_wo;
   __device__ __forceinline__ Ctx prep(int m) const {
     Ctx c;
     if (m >= M) { c.kh = -1; c.kw = c.c = 0; return c; }
@@ -235,8 +252,8 @@ struct WgradX {
     v[0] = v[1] = v[2] = v[3] = 0.f;
     if (c.kh < 0 || k >= K) return;
     const int hw = g.Ho * g.Wo;
-    const int n = k / hw, r = k - n * hw;
-    const int ho = r / g.Wo, wo = r - ho * g.Wo;
+    const int n = fast_div(k, mg_hw), r = k - n * hw;
+    const int ho = fast_div(r, mg_wo), wo = r - ho * g.Wo;
     const int hi = ho * g.stride - g.pad + c.kh, wi = wo * g.stride - g.pad + c.kw;
     if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
       const float4 t = *reinterpret_cast<const float4*>(x + ((long)((n * g.H + hi) * g.W + wi) * g.C + c.c));

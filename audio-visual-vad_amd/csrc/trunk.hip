@@ -242,8 +242,9 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
     return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
   }
   if (g.C % 32 || g.Co % 4) return AVVAD_EINVAL;
-  convop::ColTapRows b{wf, g.Co, g.Co, K, g.C, g.KS * g.KS};
-  convop::Im2colFwd a{x, g, M};
+  const int T = g.KS * g.KS;
+  convop::ColTapRows b{wf, g.Co, g.Co, K, g.C, T, convop::div_magic(T)};
+  convop::Im2colFwd a{x, g, M, convop::tap_div(T, g.KS)};
   if (g.Co <= 64) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s);
 }
@@ -280,8 +281,9 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
     return AVVAD_OK;
   }
   igemm::EpiStore e{dx, g.C, nullptr, accumulate ? 1 : 0};
-  convop::ColTapRows b{wd, g.C, g.C, K, g.Co, g.KS * g.KS};
-  convop::Im2colDgrad a{dy, g, M};
+  const int T = g.KS * g.KS;
+  convop::ColTapRows b{wd, g.C, g.C, K, g.Co, T, convop::div_magic(T)};
+  convop::Im2colDgrad a{dy, g, M, convop::tap_div(T, g.KS)};
   if (g.C <= 64) return igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s);
   return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s);
 }
@@ -298,8 +300,9 @@ static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g,
     return igemm::launch<64, 64>(a, b, e, M, g.Co, K, split, s);
   }
   if (g.C % 32) return AVVAD_EINVAL;
-  convop::EpiWgrad e{pk, g.Co, nullptr, 2, 1, g.C, g.KS * g.KS};
-  convop::WgradX a{x, g, M, K};
+  convop::EpiWgrad e{pk, g.Co, nullptr, 2, 1, g.C, g.KS * g.KS, convop::div_magic(g.KS * g.KS)};
+  if ((unsigned long)K * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
+  convop::WgradX a{x, g, M, K, convop::div_magic(g.Ho * g.Wo), convop::div_magic(g.Wo)};
   const bool small = g.Co <= 64;
   const int nb = cdiv(M, 128) * cdiv(g.Co, small ? 64 : 128);
   int split = cdiv(1024, nb); if (split > ktiles) split = ktiles;
