@@ -55,17 +55,17 @@ struct Im2colFwd {
     c.wi0 = wo * g.stride - g.pad;
     return c;
   }
-  __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int kin, float* v) const {
     const int T = g.KS * g.KS, q = k0 >> 5;  // wave-uniform (k0 % 32 == 0, C % 32 == 0)
     const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
     const int c0 = cc * 32 + kin;
     const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
     const int hi = c.hi0 + kh, wi = c.wi0 + kw;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (c.base >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
-      const float4 t = *reinterpret_cast<const float4*>(x + ((long)(c.base + hi * g.W + wi) * g.C + c0));
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
+    const bool ok = c.base >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+    const unsigned off = ok ? (unsigned)((c.base + hi * g.W + wi) * g.C + c0) : 0u;   // < 2^31 elements: launcher check
+    const float4 t = *reinterpret_cast<const float4*>(x + off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    return ok;
   }
 };
 
@@ -89,23 +89,23 @@ struct Im2colDgrad {
     c.wp = wi + g.pad;
     return c;
   }
-  __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int kin, float* v) const {
     const int T = g.KS * g.KS, q = k0 >> 5;
     const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
     const int c0 = cc * 32 + kin;
     const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
     const int th = c.hp - kh, tw = c.wp - kw;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (c.base < 0 || th < 0 || tw < 0) return;
+    bool ok = c.base >= 0 && th >= 0 && tw >= 0;
     int ho = th, wo = tw;
     if (g.stride == 2) {
-      if ((th | tw) & 1) return;
+      ok = ok && !((th | tw) & 1);
       ho >>= 1; wo >>= 1;
     }
-    if (ho < g.Ho && wo < g.Wo) {
-      const float4 t = *reinterpret_cast<const float4*>(dy + ((long)(c.base + ho * g.Wo + wo) * g.Co + c0));
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
+    ok = ok && ho < g.Ho && wo < g.Wo;
+    const unsigned off = ok ? (unsigned)((c.base + ho * g.Wo + wo) * g.Co + c0) : 0u;
+    const float4 t = *reinterpret_cast<const float4*>(dy + off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    return ok;
   }
 };
 
@@ -119,6 +119,7 @@ struct S2Class {
   int ph, pw, Hc, Wc;   // class grid
   int kh0, kw0, nkh, nkw;
   int oh, ow;           // ho = i + oh - a, wo = j + ow - b for tap (kh0 + 2a, kw0 + 2b)
+  unsigned mg_ntap, mg_nkw;   // div_magic(nkh*nkw), div_magic(nkw)
 };
 struct Im2colDgradS2 {
   static constexpr bool KCONTIG = true;
@@ -138,17 +139,17 @@ struct Im2colDgradS2 {
     x.base = n * g.Ho * g.Wo;
     return x;
   }
-  __device__ __forceinline__ void load(const Ctx& x, int, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx& x, int, int k0, int kin, float* v) const {
     const int ntap = c.nkh * c.nkw, q = k0 >> 5;
-    const int cc = q / ntap, seg = q - cc * ntap;
+    const int cc = fast_div(q, c.mg_ntap), seg = q - cc * ntap;
     const int c0 = cc * 32 + kin;
-    const int a = seg / c.nkw, b = seg - a * c.nkw;
+    const int a = fast_div(seg, c.mg_nkw), b = seg - a * c.nkw;
     const int ho = x.i + c.oh - a, wo = x.j + c.ow - b;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (x.base >= 0 && (unsigned)ho < (unsigned)g.Ho && (unsigned)wo < (unsigned)g.Wo) {
-      const float4 t = *reinterpret_cast<const float4*>(dy + ((long)(x.base + ho * g.Wo + wo) * g.Co + c0));
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
+    const bool ok = x.base >= 0 && (unsigned)ho < (unsigned)g.Ho && (unsigned)wo < (unsigned)g.Wo;
+    const unsigned off = ok ? (unsigned)((x.base + ho * g.Wo + wo) * g.Co + c0) : 0u;
+    const float4 t = *reinterpret_cast<const float4*>(dy + off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    return ok;
   }
 };
 // weight rows of the live taps in (chunk, tap, channel) K order:
@@ -161,15 +162,17 @@ struct ColSegRows {
   long ld;
   int X, K, ntap;
   int rowbase[4];
+  unsigned mg_ntap;
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
-  __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (k < K && x < X) {
-      const int q = k >> 5, cc = q / ntap, seg = q - cc * ntap;
-      const float4 t = *reinterpret_cast<const float4*>(p + (long)(rowbase[seg] + cc * 32 + (k & 31)) * ld + x);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
+    const bool ok = k < K && x < X;
+    const int q = k >> 5, cc = fast_div(q, mg_ntap), seg = (q - cc * ntap) & 3;
+    const int rb = seg == 0 ? rowbase[0] : (seg == 1 ? rowbase[1] : (seg == 2 ? rowbase[2] : rowbase[3]));  // no scratch array
+    const unsigned off = ok ? (unsigned)((rb + cc * 32 + (k & 31)) * (int)ld + x) : 0u;
+    const float4 t = *reinterpret_cast<const float4*>(p + off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    return ok;
   }
 };
 // epilogue: class-local row m -> input pixel (n, 2i+ph, 2j+pw); always accumulating (the caller zero-fills)
@@ -180,14 +183,15 @@ struct EpiS2 {
   int mode;            // 1
   int cs;
   int H, W, Hc, Wc, ph, pw;
+  unsigned mg_hw, mg_wc;   // div_magic(Hc*Wc), div_magic(Wc)
   __device__ __forceinline__ float* at(int m, int n) const {
     const int hw = Hc * Wc;
-    const int img = m / hw, r = m - img * hw;
-    const int i = r / Wc, j = r - i * Wc;
+    const int img = fast_div(m, mg_hw), r = m - img * hw;
+    const int i = fast_div(r, mg_wc), j = r - i * Wc;
     return C + ((long)(img * H + 2 * i + ph) * W + 2 * j + pw) * ldc + n;
   }
   __device__ __forceinline__ void store(int m, int n, float v) const { *at(m, n) += v; }
-  __device__ __forceinline__ void add_partial(int m, int n, float v, bool) const { atomicAdd(at(m, n), v); }
+  __device__ __forceinline__ void add_partial(int m, int n, float v) const { atomicAdd(at(m, n), v); }
 };
 
 // packed weights [(tap, ch)][x] read in (chunk, tap, channel) K order: k = (cc*T + tap)*32 + r -> row tap*C + cc*32 + r
@@ -200,14 +204,14 @@ struct ColTapRows {
   int X, K, C, T;
   unsigned mg_T;
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
-  __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (k < K && x < X) {
-      const int q = k >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;
-      const float4 t = *reinterpret_cast<const float4*>(p + (long)(tap * C + cc * 32 + (k & 31)) * ld + x);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
+    const bool ok = k < K && x < X;
+    const int q = k >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;
+    const unsigned off = ok ? (unsigned)((tap * C + cc * 32 + (k & 31)) * (int)ld + x) : 0u;
+    const float4 t = *reinterpret_cast<const float4*>(p + off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    return ok;
   }
 };
 // wgrad epilogue: GEMM row m' = (cc*T + tap)*32 + r (chunk-major, see WgradX) -> packed row tap*C + cc*32 + r; atomic
@@ -224,7 +228,7 @@ struct EpiWgrad {
     return C + (long)(tap * Cch + cc * 32 + (m & 31)) * ldc + n;
   }
   __device__ __forceinline__ void store(int m, int n, float v) const { atomicAdd(at(m, n), v); }
-  __device__ __forceinline__ void add_partial(int m, int n, float v, bool) const { atomicAdd(at(m, n), v); }
+  __device__ __forceinline__ void add_partial(int m, int n, float v) const { atomicAdd(at(m, n), v); }
 };
 
 // ---- wgrad A: A[m][k = output pixel] = x[n, ho*s-p+kh, wo*s-p+kw, c] with m = (cc*T + tap)*32 + r, c = cc*32 + r:
@@ -247,18 +251,17 @@ struct WgradX {
     c.kw = tap - c.kh * g.KS;
     return c;
   }
-  __device__ __forceinline__ void load(const Ctx& c, int, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int kin, float* v) const {
     const int k = k0 + kin;
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (c.kh < 0 || k >= K) return;
     const int hw = g.Ho * g.Wo;
     const int n = fast_div(k, mg_hw), r = k - n * hw;
     const int ho = fast_div(r, mg_wo), wo = r - ho * g.Wo;
     const int hi = ho * g.stride - g.pad + c.kh, wi = wo * g.stride - g.pad + c.kw;
-    if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
-      const float4 t = *reinterpret_cast<const float4*>(x + ((long)((n * g.H + hi) * g.W + wi) * g.C + c.c));
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
+    const bool ok = c.kh >= 0 && k < K && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+    const unsigned off = ok ? (unsigned)(((n * g.H + hi) * g.W + wi) * g.C + c.c) : 0u;
+    const float4 t = *reinterpret_cast<const float4*>(x + off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    return ok;
   }
 };
 

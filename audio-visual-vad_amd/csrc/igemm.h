@@ -23,6 +23,7 @@
 #pragma once
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace igemm {
 
@@ -34,19 +35,17 @@ struct NoCtx {};
 struct EpiStore {
   float* C;
   long ldc;
-  const float* bias;  // per column n, may be null
+  const float* bias;  // per column n, may be null (added by the kernel: once per column, before the row loop)
   int mode;           // 0 store, 1 C += v, 2 atomicAdd
   int cs = 1;         // column stride (elements)
   __device__ __forceinline__ void store(int m, int n, float v) const {
     float* p = C + (long)m * ldc + (long)n * cs;
-    if (bias) v += bias[n];
     if (mode == 0) *p = v;
     else if (mode == 1) *p += v;
     else atomicAdd(p, v);
   }
   // piece of a K-split tile: always an atomic add (the output is pre-zeroed or accumulating)
-  __device__ __forceinline__ void add_partial(int m, int n, float v, bool first) const {
-    if (bias && first) v += bias[n];
+  __device__ __forceinline__ void add_partial(int m, int n, float v) const {
     atomicAdd(C + (long)m * ldc + (long)n * cs, v);
   }
 };
@@ -64,9 +63,10 @@ struct RowPlain {
   __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
     float t = 0.f;
-    if (x < X && k < K) t = p[(long)x * ld + k];
-    v[0] = relu ? fmaxf(t, 0.f) : t;
+    if (x < X && k < K) t = p[(long)x * ld + k];   // scalar guarded loads: cheaper here than 16 clamped 64-bit offsets
+    v[0] = t;
   }
+  __device__ __forceinline__ float post(float v) const { return relu ? fmaxf(v, 0.f) : v; }
 };
 
 // element (x, k) = p[b*bstride + x*ld + t + shift], k = b*seglen + t   (batch-segmented K:
@@ -87,8 +87,9 @@ struct RowSegK {
       const int c = x / fw, tap = x - c * fw;
       t = p[(long)b * bstride + (long)c * ld + tt + shift + tap * dil];
     }
-    v[0] = relu ? fmaxf(t, 0.f) : t;
+    v[0] = t;
   }
+  __device__ __forceinline__ float post(float v) const { return relu ? fmaxf(v, 0.f) : v; }
 };
 
 // element (k, x) = p[k*ld + x]
@@ -101,24 +102,42 @@ struct ColPlain {
   long ld;
   int X, K, relu;
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
-  __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
-#pragma unroll
-    for (int j = 0; j < V; ++j) v[j] = 0.f;
-    if (k < K && x < X) {  // V==4: X % 4 == 0 is a launch precondition
-      if (V == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p + (long)k * ld + x);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else {
-        v[0] = p[(long)k * ld + x];
-      }
+    const bool ok = k < K && x < X;  // V==4: X % 4 == 0 and 16-byte aligned rows are launch preconditions
+    const long off = ok ? (long)k * ld + x : 0;
+    if (V == 4) {
+      const float4 t = *reinterpret_cast<const float4*>(p + off);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+      v[0] = p[off];
     }
-    if (relu) {
-#pragma unroll
-      for (int j = 0; j < V; ++j) v[j] = fmaxf(v[j], 0.f);
-    }
+    return ok;
   }
+  __device__ __forceinline__ float post(float v) const { return relu ? fmaxf(v, 0.f) : v; }
 };
+
+#ifdef AVVAD_PROF
+// tuning aid (never in the shipped build): per-phase shader-clock totals of wave 0 of every workgroup
+__device__ unsigned long long g_prof[8];   // 0 segments, 1 prologue, 2 loop, 3 barrier wait, 4 staging, 5 epilogue, 6 ktile iterations
+#define PROF_T() ((wave == 0) ? __builtin_amdgcn_s_memtime() : 0ull)
+#define PROF_ADD(i, v) do { if (t == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
+#else
+#define PROF_T() 0ull
+#define PROF_ADD(i, v) do { } while (0)
+#endif
+
+// OPERAND CONTRACT.  load() issues its global load UNCONDITIONALLY (from offset 0 of the operand when the element is
+// out of range or padding) and returns whether the element is real; it does no arithmetic on the loaded value.  The
+// zero-fill of invalid elements and an operand's optional elementwise map (post(): the fused ReLU of the dense
+// operands) happen when the staged registers are written to LDS.  Anything that touches a just-loaded value inside
+// load() -- a select, an fmaxf, even a register shuffle behind a guarded load -- makes hipcc wait for the load on the
+// spot (s_waitcnt vmcnt(0) behind each global_load), which serialises the prefetch and exposes its full latency in the
+// middle of the MFMA stream.  (Older functors whose load() returns void zero their own values; they still work.)
+template <class Op, class = void>
+struct HasPost : std::false_type {};
+template <class Op>
+struct HasPost<Op, std::void_t<decltype(&Op::post)>> : std::true_type {};
 
 // ---------------------------------------------------------------- the kernel
 template <class Op, int BX, int NTH>
@@ -137,7 +156,16 @@ struct Stage {
       else { xl = t % BX; kl = t / BX + (NTH / BX) * i; }
     }
   }
-  __device__ static __forceinline__ void to_lds(float* S, int t, const float (&st)[NV][VEC]) {
+  __device__ static __forceinline__ void to_lds(float* S, int t, const float (&st0)[NV][VEC], const Op& op, unsigned okmask) {
+    float st[NV][VEC];
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v = st0[i][j];
+        if constexpr (HasPost<Op>::value) v = op.post(v);
+        st[i][j] = ((okmask >> i) & 1u) ? v : 0.f;
+      }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       int xl, kl;
@@ -214,12 +242,32 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
     for (int i = 0; i < SB::NCTX; ++i) { int xl, kl; SB::coord(t, i, xl, kl); bctx[i] = B.prep(n0 + xl); }
 
     float sa[SA::NV][SA::VEC], sb[SB::NV][SB::VEC];
+    unsigned oka = ~0u, okb = ~0u;   // bit i: staged vector i holds a real element (see OPERAND CONTRACT)
+    static_assert(SA::NV <= 32 && SB::NV <= 32, "validity masks are 32 bits");
     auto gload = [&](int kt) {
+#ifdef AVVAD_ABL_HOT
+      const int k0 = (kt & 1) * BK;
+#else
       const int k0 = kt * BK;
+#endif
+      constexpr bool AB = std::is_same<decltype(A.load(actx[0], 0, 0, 0, sa[0])), bool>::value;
+      constexpr bool BB = std::is_same<decltype(B.load(bctx[0], 0, 0, 0, sb[0])), bool>::value;
+      if (AB) oka = 0u;
+      if (BB) okb = 0u;
 #pragma unroll
-      for (int i = 0; i < SA::NV; ++i) { int xl, kl; SA::coord(t, i, xl, kl); A.load(actx[AOp::KCONTIG ? i : 0], m0 + xl, k0, kl, sa[i]); }
+      for (int i = 0; i < SA::NV; ++i) {
+        int xl, kl;
+        SA::coord(t, i, xl, kl);
+        if constexpr (AB) oka |= (unsigned)A.load(actx[AOp::KCONTIG ? i : 0], m0 + xl, k0, kl, sa[i]) << i;
+        else A.load(actx[AOp::KCONTIG ? i : 0], m0 + xl, k0, kl, sa[i]);
+      }
 #pragma unroll
-      for (int i = 0; i < SB::NV; ++i) { int xl, kl; SB::coord(t, i, xl, kl); B.load(bctx[BOp::KCONTIG ? i : 0], n0 + xl, k0, kl, sb[i]); }
+      for (int i = 0; i < SB::NV; ++i) {
+        int xl, kl;
+        SB::coord(t, i, xl, kl);
+        if constexpr (BB) okb |= (unsigned)B.load(bctx[BOp::KCONTIG ? i : 0], n0 + xl, k0, kl, sb[i]) << i;
+        else B.load(bctx[BOp::KCONTIG ? i : 0], n0 + xl, k0, kl, sb[i]);
+      }
     };
 
     f32x16 acc[TM][TN];
@@ -231,12 +279,15 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // prologue: tile kt0 -> LDS buffer 0, tile kt0+1 -> registers
+    const unsigned long long tp0 = PROF_T();
+    unsigned long long tbar = 0, tstage = 0;
     gload(kt0);
     __syncthreads();  // the previous segment's LDS reads are done
-    SA::to_lds(smem, t, sa);
-    SB::to_lds(smem + BK * SA::LD, t, sb);
+    SA::to_lds(smem, t, sa, A, oka);
+    SB::to_lds(smem + BK * SA::LD, t, sb, B, okb);
     if (kt0 + 1 < kt1) gload(kt0 + 1);
     __syncthreads();
+    const unsigned long long tp1 = PROF_T();
 
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = DB ? ((kt - kt0) & 1) : 0;
@@ -257,16 +308,24 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
           // halves of this tile's MFMAs instead of right behind the barrier, where every wave of both co-resident
           // workgroups would do them at the same time with the matrix pipe idle.
           float* An = smem + (cur ^ 1) * TILE;
-          SA::to_lds(An, t, sa);
-          SB::to_lds(An + BK * SA::LD, t, sb);
+          const unsigned long long ts0 = PROF_T();
+#ifndef AVVAD_ABL_NOLDSW
+          SA::to_lds(An, t, sa, A, oka);
+          SB::to_lds(An + BK * SA::LD, t, sb, B, okb);
+#endif
+#ifndef AVVAD_ABL_NOGLOAD
           if (kt + 2 < kt1) gload(kt + 2);
+#endif
+          tstage += PROF_T() - ts0;
         }
+#ifndef AVVAD_ABL_NODSR
         if (ks + 1 < BK / 2) {  // fragments of the next k-step are in flight under this step's MFMAs
 #pragma unroll
           for (int i = 0; i < TM; ++i) a[(ks + 1) & 1][i] = ap[(ks + 1) * 2 * SA::LD + i * 32];
 #pragma unroll
           for (int j = 0; j < TN; ++j) b[(ks + 1) & 1][j] = bp[(ks + 1) * 2 * SB::LD + j * 32];
         }
+#endif
         // pin the prefetch ABOVE this step's MFMAs: left alone, hipcc sinks the ds_reads below them (operand
         // registers get reused) and every k-step then eats the LDS latency in front of its MFMAs
         __builtin_amdgcn_sched_barrier(0);
@@ -275,30 +334,68 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[ks & 1][i], b[ks & 1][j], acc[i][j]);
       }
+#ifndef AVVAD_ABL_NOBAR
+      const unsigned long long tb0 = PROF_T();
       __syncthreads();
+      tbar += PROF_T() - tb0;
+#endif
       if (!DB && kt + 1 < kt1) {  // single LDS buffer (more workgroups per CU): restage after everyone has read
-        SA::to_lds(smem, t, sa);
-        SB::to_lds(smem + BK * SA::LD, t, sb);
+        SA::to_lds(smem, t, sa, A, oka);
+        SB::to_lds(smem + BK * SA::LD, t, sb, B, okb);
         if (kt + 2 < kt1) gload(kt + 2);
         __syncthreads();
       }
     }
 
     const bool whole = (kt0 == 0 && kt1 == ktiles);
+    const unsigned long long tp2 = PROF_T();
+    // Epilogue.  The column's bias is fetched once (a load + wait per element costs a memory round trip each).  Plain
+    // row-major outputs that fit 32-bit offsets take the fast path: interior tiles skip the per-element range checks
+    // and every store is one v_add on a 32-bit offset against the scalar base (global_store_dword v, v, s[C]).
+    bool fast = false;
+    if constexpr (std::is_same<Epi, EpiStore>::value) fast = E.cs == 1 && (long)M * E.ldc < (1L << 31) && m0 + BM <= M && n0 + BN <= N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WGN) + j * 32 + li;
+        const float bv = (E.bias && n < N && kt0 == 0) ? E.bias[n] : 0.f;
+        const int mb = m0 + wm * (BM / 2) + i * 32;
+        if constexpr (std::is_same<Epi, EpiStore>::value) {
+          if (fast) {
+            const unsigned ld32 = (unsigned)E.ldc;
+            const unsigned base = (unsigned)(mb + 4 * lh) * ld32 + (unsigned)n;
+            float* const Cb = E.C;
+            if (!whole || E.mode == 2) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) atomicAdd(Cb + (base + (unsigned)mfma32_row(r, 0) * ld32), acc[i][j][r] + bv);
+            } else if (E.mode == 0) {
+#pragma unroll
+              for (int r = 0; r < 16; ++r) Cb[base + (unsigned)mfma32_row(r, 0) * ld32] = acc[i][j][r] + bv;
+            } else {
+              float old[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) old[r] = Cb[base + (unsigned)mfma32_row(r, 0) * ld32];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) Cb[base + (unsigned)mfma32_row(r, 0) * ld32] = old[r] + acc[i][j][r] + bv;
+            }
+            continue;
+          }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = m0 + wm * (BM / 2) + i * 32 + mfma32_row(r, lh);
+          const int m = mb + mfma32_row(r, lh);
           if (m < M && n < N) {
-            if (whole) E.store(m, n, acc[i][j][r]);
-            else E.add_partial(m, n, acc[i][j][r], kt0 == 0);
+            if (whole) E.store(m, n, acc[i][j][r] + bv);
+            else E.add_partial(m, n, acc[i][j][r] + bv);
           }
         }
       }
+#ifdef AVVAD_PROF
+    const unsigned long long tp3 = PROF_T();
+    PROF_ADD(0, 1); PROF_ADD(1, tp1 - tp0); PROF_ADD(2, tp2 - tp1); PROF_ADD(3, tbar); PROF_ADD(4, tstage); PROF_ADD(5, tp3 - tp2);
+    PROF_ADD(6, kt1 - kt0);
+#endif
   }
 }
 

@@ -233,6 +233,7 @@ __global__ void zero_f32(float* p, long n) {
 static inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
 // ------------------------------------------------------------------ conv launchers
+static inline bool fits_u31(long n) { return n >= 0 && n < (1L << 31); }
 static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s) {
   const int M = g.N * g.Ho * g.Wo, K = g.KS * g.KS * g.C;
   igemm::EpiStore e{y, g.Co, nullptr, 0};
@@ -242,6 +243,7 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
     return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
   }
   if (g.C % 32 || g.Co % 4) return AVVAD_EINVAL;
+  if (!fits_u31((long)g.N * g.H * g.W * g.C) || !fits_u31((long)K * g.Co)) return AVVAD_EINVAL;   // 32-bit gather offsets
   const int T = g.KS * g.KS;
   convop::ColTapRows b{wf, g.Co, g.Co, K, g.C, T, convop::div_magic(T)};
   convop::Im2colFwd a{x, g, M, convop::tap_div(T, g.KS)};
@@ -252,6 +254,7 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
 static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s) {
   const int M = g.N * g.H * g.W, K = g.KS * g.KS * g.Co;
   if (g.Co % 32 || g.C % 4) return AVVAD_EINVAL;
+  if (!fits_u31((long)g.N * g.Ho * g.Wo * g.Co) || !fits_u31((long)K * g.C)) return AVVAD_EINVAL;   // 32-bit gather offsets
   if (g.stride == 2) {
     // parity-class decomposition (conv_ops.h): 4 small GEMMs over live taps only, accumulating into dx
     if (!accumulate) hipLaunchKernelGGL(zero_f32, dim3(ew_grid((long)M * g.C)), dim3(256), 0, s, dx, (long)M * g.C);
@@ -267,12 +270,14 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
         const int Mc = g.N * c.Hc * c.Wc, ntap = c.nkh * c.nkw;
         if (Mc <= 0 || ntap <= 0) continue;
         if (ntap > 4) return AVVAD_EINVAL;
+        c.mg_ntap = convop::div_magic(ntap); c.mg_nkw = convop::div_magic(c.nkw);
         convop::Im2colDgradS2 a{dy, g, c, Mc};
-        convop::ColSegRows b{wd, g.C, g.C, ntap * g.Co, ntap, {0, 0, 0, 0}};
+        convop::ColSegRows b{wd, g.C, g.C, ntap * g.Co, ntap, {0, 0, 0, 0}, convop::div_magic(ntap)};
         for (int ia = 0; ia < c.nkh; ++ia)
           for (int ib = 0; ib < c.nkw; ++ib)
             b.rowbase[ia * c.nkw + ib] = ((c.kh0 + 2 * ia) * g.KS + (c.kw0 + 2 * ib)) * g.Co;
-        convop::EpiS2 e{dx, g.C, nullptr, 1, 1, g.H, g.W, c.Hc, c.Wc, ph, pw};
+        convop::EpiS2 e{dx, g.C, nullptr, 1, 1, g.H, g.W, c.Hc, c.Wc, ph, pw, convop::div_magic(c.Hc * c.Wc), convop::div_magic(c.Wc)};
+        if ((unsigned long)(Mc + 128) * (unsigned long)(c.Hc * c.Wc) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
         int rc;
         if (g.C <= 64) rc = igemm::launch<128, 64>(a, b, e, Mc, g.C, ntap * g.Co, 1, s);
         else rc = igemm::launch<128, 128>(a, b, e, Mc, g.C, ntap * g.Co, 1, s);
@@ -301,7 +306,8 @@ static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g,
   }
   if (g.C % 32) return AVVAD_EINVAL;
   convop::EpiWgrad e{pk, g.Co, nullptr, 2, 1, g.C, g.KS * g.KS, convop::div_magic(g.KS * g.KS)};
-  if ((unsigned long)K * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
+  if ((unsigned long)(K + igemm::BK) * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
+  if (!fits_u31((long)g.N * g.H * g.W * g.C)) return AVVAD_EINVAL;                                              // 32-bit gather offsets
   convop::WgradX a{x, g, M, K, convop::div_magic(g.Ho * g.Wo), convop::div_magic(g.Wo)};
   const bool small = g.Co <= 64;
   const int nb = cdiv(M, 128) * cdiv(g.Co, small ? 64 : 128);
@@ -387,6 +393,13 @@ extern "C" int avvad_conv2d_fwd(const float* x, const float* wf, float* y, const
   if (!x || !wf || !y || !conv_geom(d, &g)) return AVVAD_EINVAL;
   return conv_fwd(x, wf, y, g, (hipStream_t)s);
 }
+#ifdef AVVAD_PROF
+extern "C" int avvad_debug_prof(unsigned long long* out, int reset) {
+  if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(igemm::g_prof), sizeof(unsigned long long) * 8);
+  if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(igemm::g_prof), z, sizeof(z)); }
+  return 0;
+}
+#endif
 extern "C" int avvad_conv2d_dgrad(const float* dy, const float* wd, float* dx, const avvad_conv_desc* d, int accumulate,
                                   avvad_stream_t s) {
   AVVAD_ENTER();

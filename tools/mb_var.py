@@ -3,7 +3,7 @@ sys.argv=[sys.argv[0]]
 R=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0]=[os.path.join(R,'tools')]
 import microbench as mb
-for var in ('sb','w8'):
+for var in ('w8',):
     os.environ['AVVAD_IGEMM_VARIANT']=var
     print('variant',var)
     for n in (1024,):

@@ -9,7 +9,18 @@ lib = L.lib()
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 def timeit(fn, reps=10):
+    """Sustained timing: the chip's clock ramps for tens of ms after idle, so a 3+10-launch burst of sub-ms kernels
+    under-reports by 10-20 %.  Warm for AVVAD_MB_WARM seconds (default 0.5) of back-to-back launches, then time >= 0.25 s."""
+    import time
+    warm = float(os.environ.get("AVVAD_MB_WARM", "0.5"))
     for _ in range(3): fn()
+    torch.cuda.synchronize()
+    t0 = time.time(); n = 0
+    while time.time() - t0 < warm:
+        for _ in range(20): fn()
+        torch.cuda.synchronize(); n += 20
+    per = max((time.time() - t0) / max(n, 1), 1e-6)
+    reps = max(reps, int(0.25 / per))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps): fn()
