@@ -7,7 +7,7 @@
 
 constexpr int BN_MAXC = 1024;
 constexpr int MAXC = BN_MAXC;
-constexpr int STAT_CHUNKS = 256;
+constexpr int STAT_CHUNKS = 1024;   // workgroups of a column reduction (4 per CU)
 
 // ------------------------------------------------------------------ column reductions ([M][C] fp32 -> per-channel fp64 sums)
 // MODE 0: sum x, sum x^2           (batch statistics)
@@ -29,26 +29,42 @@ __global__ void __launch_bounds__(256)
   }
   const long r0 = blockIdx.x * rows_per_chunk;
   const long r1 = min(M, r0 + rows_per_chunk);
+  // 4 rows per trip: all loads of the trip are issued before any is consumed (one row per trip left a 256-block grid
+  // with ~3 MB in flight -- latency-bound at a third of the HBM rate)
+  constexpr int U = 4;
   if (rl < RL)
-    for (long r = r0 + rl; r < r1; r += RL) {
-      const long o = r * C + q * 4;
-      const float4 v = *reinterpret_cast<const float4*>(x + o);
-      const float xv[4] = {v.x, v.y, v.z, v.w};
-      if (MODE == 0) {
+    for (long r = r0 + rl; r < r1; r += (long)U * RL) {
+      float4 xv4[U], dv4[U], yv4[U];
+      bool live[U];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[j] += xv[j]; ss[j] += (double)xv[j] * xv[j]; }
-      } else {
-        const float4 d = *reinterpret_cast<const float4*>(dy + o);
-        float g[4] = {d.x, d.y, d.z, d.w};
-        if (ymask) {
-          const float4 y = *reinterpret_cast<const float4*>(ymask + o);
-          if (!(y.x > 0.f)) g[0] = 0.f;
-          if (!(y.y > 0.f)) g[1] = 0.f;
-          if (!(y.z > 0.f)) g[2] = 0.f;
-          if (!(y.w > 0.f)) g[3] = 0.f;
+      for (int u = 0; u < U; ++u) {
+        const long rr = r + (long)u * RL;
+        live[u] = rr < r1;
+        const long o = (live[u] ? rr : r) * C + q * 4;
+        xv4[u] = *reinterpret_cast<const float4*>(x + o);
+        if (MODE == 1) {
+          dv4[u] = *reinterpret_cast<const float4*>(dy + o);
+          if (ymask) yv4[u] = *reinterpret_cast<const float4*>(ymask + o);
         }
+      }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { s[j] += g[j]; ss[j] += (double)g[j] * ((xv[j] - mu[j]) * is[j]); }
+      for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+        const float xv[4] = {xv4[u].x, xv4[u].y, xv4[u].z, xv4[u].w};
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s[j] += xv[j]; ss[j] += (double)xv[j] * xv[j]; }
+        } else {
+          float g[4] = {dv4[u].x, dv4[u].y, dv4[u].z, dv4[u].w};
+          if (ymask) {
+            if (!(yv4[u].x > 0.f)) g[0] = 0.f;
+            if (!(yv4[u].y > 0.f)) g[1] = 0.f;
+            if (!(yv4[u].z > 0.f)) g[2] = 0.f;
+            if (!(yv4[u].w > 0.f)) g[3] = 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { s[j] += g[j]; ss[j] += (double)g[j] * ((xv[j] - mu[j]) * is[j]); }
+        }
       }
     }
 #pragma unroll
@@ -63,20 +79,22 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// sum the per-chunk partials of channel c = blockIdx.x*32 + (tid&31): 8 chunk-lanes per channel, fixed order
-// (deterministic); every thread of the 256-thread block must call it; lanes tid < 32 get the totals.
+// sum the per-chunk partials of channel c = blockIdx.x*FIN_CH + (tid % FIN_CH): 256/FIN_CH chunk-lanes per channel,
+// fixed order (deterministic); every thread of the 256-thread block must call it; lanes tid < FIN_CH get the totals.
+constexpr int FIN_CH = 8;    // channels per finalize block (grid = ceil(C / FIN_CH))
 __device__ __forceinline__ void chunk_sums(const double* __restrict__ part, int nchunk, int C, double& s, double& ss) {
-  __shared__ double sm[2][8][32];
-  const int cl = threadIdx.x & 31, kl = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+  constexpr int KL = 256 / FIN_CH;
+  __shared__ double sm[2][KL][FIN_CH];
+  const int cl = threadIdx.x % FIN_CH, kl = threadIdx.x / FIN_CH;
+  const int c = blockIdx.x * FIN_CH + cl;
   double a = 0, b = 0;
   if (c < C)
-    for (int i = kl; i < nchunk; i += 8) { a += part[((long)i * 2 + 0) * C + c]; b += part[((long)i * 2 + 1) * C + c]; }
+    for (int i = kl; i < nchunk; i += KL) { a += part[((long)i * 2 + 0) * C + c]; b += part[((long)i * 2 + 1) * C + c]; }
   sm[0][kl][cl] = a; sm[1][kl][cl] = b;
   __syncthreads();
   s = 0; ss = 0;
   if (kl == 0)
-    for (int k = 0; k < 8; ++k) { s += sm[0][k][cl]; ss += sm[1][k][cl]; }
+    for (int k = 0; k < KL; ++k) { s += sm[0][k][cl]; ss += sm[1][k][cl]; }
 }
 
 // finalize batch statistics -> scale/shift (+ saved mean/invstd, running-stat update)
@@ -86,8 +104,8 @@ __global__ void bn_finalize(const double* __restrict__ part, int nchunk, long M,
                             float* __restrict__ mean_o, float* __restrict__ invstd_o) {
   double s = 0, ss = 0;
   if (training) chunk_sums(part, nchunk, C, s, ss);
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  if (c >= C || threadIdx.x >= 32) return;
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH);
+  if (c >= C || threadIdx.x >= FIN_CH) return;
   float mean, var;
   if (training) {
     const double m = s / (double)M;
@@ -115,8 +133,8 @@ __global__ void bn_bwd_finalize(const double* __restrict__ part, int nchunk, lon
                                 float* __restrict__ dbeta, float* __restrict__ coef) {
   double s = 0, ss = 0;
   chunk_sums(part, nchunk, C, s, ss);
-  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
-  if (c >= C || threadIdx.x >= 32) return;
+  const int c = blockIdx.x * FIN_CH + (threadIdx.x % FIN_CH);
+  if (c >= C || threadIdx.x >= FIN_CH) return;
   if (dbeta) dbeta[c] += (float)s;
   if (dgamma) dgamma[c] += (float)ss;
   coef[c] = gamma[c] * invstd[c];
@@ -127,19 +145,33 @@ __global__ void bn_bwd_finalize(const double* __restrict__ part, int nchunk, lon
 // ------------------------------------------------------------------ fused elementwise (16-byte accesses, C % 4 == 0)
 __device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return fmaf(x, sc, sh); }
 
+// The elementwise kernels run 256-thread blocks with a grid-stride loop: the stride (gridDim*256 quads) is a multiple
+// of C/4 whenever C/4 divides 256, so a thread's channel quad never changes and its per-channel coefficients are
+// loaded ONCE into registers -- per-iteration coefficient loads (up to 20 scalar loads per float4 of data) made these
+// kernels TA-issue-bound at ~1/3 of the HBM rate.  Other C fall back to reloading each iteration.
+__device__ __forceinline__ float4 ld4(const float* p, int c) { return *reinterpret_cast<const float4*>(p + c); }
+
 // y = [relu]( x*scale+shift  [+ idn | + idn*iscale+ishift] )
-__global__ void bn_act(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
-                       const float* __restrict__ idn, const float* __restrict__ iscale, const float* __restrict__ ishift,
-                       float* __restrict__ y, long nquad, int C, int relu) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquad; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)((i * 4) % C);
+__global__ void __launch_bounds__(256)
+    bn_act(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
+           const float* __restrict__ idn, const float* __restrict__ iscale, const float* __restrict__ ishift,
+           float* __restrict__ y, long nquad, int C, int relu) {
+  const bool fixed = (256 % (C >> 2)) == 0;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = (int)((i * 4) % C);
+  float4 sc = ld4(scale, c), sh = ld4(shift, c), a = make_float4(0, 0, 0, 0), b = a;
+  if (iscale) { a = ld4(iscale, c); b = ld4(ishift, c); }
+  for (; i < nquad; i += (long)gridDim.x * blockDim.x) {
+    if (!fixed) {
+      c = (int)((i * 4) % C);
+      sc = ld4(scale, c); sh = ld4(shift, c);
+      if (iscale) { a = ld4(iscale, c); b = ld4(ishift, c); }
+    }
     const float4 v = reinterpret_cast<const float4*>(x)[i];
-    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
     float o[4] = {bn_affine(v.x, sc.x, sh.x), bn_affine(v.y, sc.y, sh.y), bn_affine(v.z, sc.z, sh.z), bn_affine(v.w, sc.w, sh.w)};
     if (idn) {
       const float4 d = reinterpret_cast<const float4*>(idn)[i];
       if (iscale) {
-        const float4 a = *reinterpret_cast<const float4*>(iscale + c), b = *reinterpret_cast<const float4*>(ishift + c);
         o[0] += bn_affine(d.x, a.x, b.x); o[1] += bn_affine(d.y, a.y, b.y);
         o[2] += bn_affine(d.z, a.z, b.z); o[3] += bn_affine(d.w, a.w, b.w);
       } else { o[0] += d.x; o[1] += d.y; o[2] += d.z; o[3] += d.w; }
@@ -151,11 +183,19 @@ __global__ void bn_act(const float* __restrict__ x, const float* __restrict__ sc
 
 // dx = k0*(g - k1 - xhat*k2), g = dy*(ymask>0);  optionally also writes g (identity branch of the residual)
 // (dx may alias dy: each element is read, then written, by the same thread)
-__global__ void bn_bwd_apply(const float* __restrict__ x, const float* dy, const float* __restrict__ ymask,
-                             const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
-                             float* dx, float* gout, long nquad, int C) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nquad; i += (long)gridDim.x * blockDim.x) {
-    const int c = (int)((i * 4) % C);
+__global__ void __launch_bounds__(256)
+    bn_bwd_apply(const float* __restrict__ x, const float* dy, const float* __restrict__ ymask,
+                 const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
+                 float* dx, float* gout, long nquad, int C) {
+  const bool fixed = (256 % (C >> 2)) == 0;
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  int c = (int)((i * 4) % C);
+  float4 mu = ld4(mean, c), is = ld4(invstd, c), k0 = ld4(coef, c), k1 = ld4(coef + MAXC, c), k2 = ld4(coef + 2 * MAXC, c);
+  for (; i < nquad; i += (long)gridDim.x * blockDim.x) {
+    if (!fixed) {
+      c = (int)((i * 4) % C);
+      mu = ld4(mean, c); is = ld4(invstd, c); k0 = ld4(coef, c); k1 = ld4(coef + MAXC, c); k2 = ld4(coef + 2 * MAXC, c);
+    }
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     const float4 d = reinterpret_cast<const float4*>(dy)[i];
     float g[4] = {d.x, d.y, d.z, d.w};
@@ -167,14 +207,15 @@ __global__ void bn_bwd_apply(const float* __restrict__ x, const float* dy, const
       if (!(y.w > 0.f)) g[3] = 0.f;
     }
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
+    const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};
+    const float a4[4] = {k0.x, k0.y, k0.z, k0.w}, b4[4] = {k1.x, k1.y, k1.z, k1.w}, c4[4] = {k2.x, k2.y, k2.z, k2.w};
     float o[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float xh = (xs[j] - mean[c + j]) * invstd[c + j];
-      o[j] = coef[c + j] * (g[j] - coef[MAXC + c + j] - xh * coef[2 * MAXC + c + j]);
+      const float xh = (xs[j] - m4[j]) * i4[j];
+      o[j] = a4[j] * (g[j] - b4[j] - xh * c4[j]);
     }
     reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (gout) reinterpret_cast<float4*>(gout)[i] = make_float4(g[0], g[1], g[2], g[3]);
   }
 }
-

@@ -439,10 +439,14 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
     }
     // (AVVAD_SKIP_ZERO: timing aid for bench.py's roofline probe, which wants the GEMM kernel's own duration --
     // the zero-fill is a separate kernel with its own line in the rocprof summary; results are garbage with it set)
-    if (e.mode == 0 && !getenv("AVVAD_SKIP_ZERO")) {  // split pieces are atomically added: the output must start at zero
-      const long n = (long)M * N;
-      hipLaunchKernelGGL(zero_strided, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s, e.C, M, N,
-                         e.ldc, e.cs);
+    if (e.mode == 0 && !getenv("AVVAD_SKIP_ZERO")) {  // split pieces are atomically added: their tiles must start at zero
+      // only the stream-K round's tiles (the last `rem`, in row-major tile order) are added to; the tile rows from the
+      // first of them down cover them -- the data-parallel tiles caught in that band are overwritten by plain stores
+      const long row0 = (full_rounds * G / cdiv(N, BN)) * BM;
+      const long n = (long)(M - row0) * N;
+      if (n > 0)
+        hipLaunchKernelGGL(zero_strided, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,
+                           e.C + row0 * e.ldc, (int)(M - row0), N, e.ldc, e.cs);
     }
   }
   const int fr = (int)full_rounds, rt = (int)rem;

@@ -180,7 +180,7 @@ extern "C" int avvad_mcb_fusion_fwd(const float* audio, const float* video, cons
   if (d->training)
     hipLaunchKernelGGL(col_reduce<0>, dim3(c.n), dim3(256), 0, s, w.Y2, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (long)d->rows, d->D, c.per, w.part);
-  hipLaunchKernelGGL(bn_finalize, dim3(cdiv(d->D, 32)), dim3(256), 0, s, w.part, c.n, (long)d->rows, d->D, bn_w, bn_b, bn_rm,
+  hipLaunchKernelGGL(bn_finalize, dim3(cdiv(d->D, FIN_CH)), dim3(256), 0, s, w.part, c.n, (long)d->rows, d->D, bn_w, bn_b, bn_rm,
                      bn_rv, d->training, d->momentum, d->eps, w.scale, w.shift, w.mean, w.invstd);
   hipLaunchKernelGGL(bn_act, dim3(ew_grid(n / 4)), dim3(256), 0, s, w.Y2, w.scale, w.shift, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, out, n / 4, d->D, 0);
@@ -201,7 +201,7 @@ extern "C" int avvad_mcb_fusion_bwd(const float* audio, const float* video, cons
   const Chunks c = chunks(d->rows, d->D);
   hipLaunchKernelGGL(col_reduce<1>, dim3(c.n), dim3(256), 0, s, w.Y2, dout, (const float*)nullptr, w.mean, w.invstd,
                      (long)d->rows, d->D, c.per, w.part);
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(d->D, 32)), dim3(256), 0, s, w.part, c.n, (long)d->rows, d->D, bn_w, w.invstd,
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(d->D, FIN_CH)), dim3(256), 0, s, w.part, c.n, (long)d->rows, d->D, bn_w, w.invstd,
                      d->training, dbn_w, dbn_b, w.coef);
   hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid(n / 4)), dim3(256), 0, s, w.Y2, dout, (const float*)nullptr, w.mean, w.invstd,
                      w.coef, w.G, (float*)nullptr, n / 4, d->D);

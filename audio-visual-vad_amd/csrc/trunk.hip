@@ -338,7 +338,7 @@ static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, cons
     hipLaunchKernelGGL(col_reduce<0>, dim3(sc.nchunk), dim3(256), 0, s, craw, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, M, C, sc.rows_per_chunk, sc.part);
   }
-  hipLaunchKernelGGL(bn_finalize, dim3(cdiv(C, 32)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], prm->bn_b[i],
+  hipLaunchKernelGGL(bn_finalize, dim3(cdiv(C, FIN_CH)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], prm->bn_b[i],
                      prm->bn_rm[i], prm->bn_rv[i], d->training, d->momentum, d->eps, ws + p->bn_scale + i * MAXC,
                      ws + p->bn_shift + i * MAXC, ws + p->bn_mean + i * MAXC, ws + p->bn_invstd + i * MAXC);
   AVVAD_LAUNCH_CHECK();
@@ -355,7 +355,7 @@ static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float
   const float* invstd = ws + p->bn_invstd + i * MAXC;
   hipLaunchKernelGGL(col_reduce<1>, dim3(sc.nchunk), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, M, C,
                      sc.rows_per_chunk, sc.part);
-  hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, 32)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], invstd,
+  hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, FIN_CH)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], invstd,
                      d->training, g->bn_w[i], g->bn_b[i], ws + p->coef);
   const long nq = M * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid(nq)), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, ws + p->coef, dx, gout,
