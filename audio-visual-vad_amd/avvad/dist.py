@@ -99,6 +99,15 @@ class BucketReducer:
             return
         s, e, _ = self.buckets[b]
         self.launched[b] = True
+        if self.flat_grad.is_cuda:
+            # A bucket can hold gradients written on different HIP streams (the audio encoder's backward runs on the
+            # side stream, ops.side_stream()); the collective is ordered after the CURRENT stream only, so make that
+            # stream wait for everything the others have been given so far (all of this bucket's writers are enqueued).
+            from . import ops
+            cur = torch.cuda.current_stream()
+            for st in ops.side_streams() + [torch.cuda.default_stream()]:
+                if st != cur:
+                    cur.wait_stream(st)
         self.handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def finish(self):

@@ -15,6 +15,27 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_SIDE = {}
+
+
+def side_stream():
+    """The per-device side HIP stream on which independent sub-graphs (the audio encoder) run next to the main one."""
+    dev = torch.cuda.current_device()
+    if dev not in _SIDE:
+        import os
+        _SIDE[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("AVVAD_SIDE_PRIO", "0")))
+    return _SIDE[dev]
+
+
+def side_streams():
+    return list(_SIDE.values())
+
+
+def overlap_enabled():
+    import os
+    return os.environ.get("AVVAD_OVERLAP", "1") != "0"
+
+
 def _dev(t, name):
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise L.AvvadError("%s must be a GPU tensor: the AV-VAD hot path has no CPU fallback "

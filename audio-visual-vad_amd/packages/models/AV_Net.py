@@ -46,9 +46,21 @@ class DeepVAD_AV(nn.Module):
             weights_init_normal(m, mean=mean, std=std)
 
     def forward(self, audio, video, lengths):
-        feats = avnn.video_features(self.features, video, self.training)          # (B,T,512)
-        if hasattr(self, "wavenet_en"):
-            audio = ops.TransposeLast2Fn.apply(self.wavenet_en(audio))            # (B,T,Bn)
+        if hasattr(self, "wavenet_en") and audio.is_cuda and ops.overlap_enabled():
+            # The audio encoder (HBM-bound Conv1d stack) and the video trunk (MFMA-bound Conv2d tower) are independent
+            # until the fusion: run the encoder on a side HIP stream so the two kinds of kernel share the chip.
+            # autograd replays each backward node on its forward stream, so the backward passes overlap the same way.
+            main, side = torch.cuda.current_stream(), ops.side_stream()
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                audio = ops.TransposeLast2Fn.apply(self.wavenet_en(audio))        # (B,T,Bn)
+            feats = avnn.video_features(self.features, video, self.training)      # (B,T,512)
+            main.wait_stream(side)
+            audio.record_stream(main)
+        else:
+            feats = avnn.video_features(self.features, video, self.training)      # (B,T,512)
+            if hasattr(self, "wavenet_en"):
+                audio = ops.TransposeLast2Fn.apply(self.wavenet_en(audio))        # (B,T,Bn)
         if self.use_mcb:
             # sketch + circular convolution -> signed sqrt -> whole-tensor L2 norm -> BatchNorm1d, fused (csrc/mcb.hip)
             bn = self.mcb_bn
