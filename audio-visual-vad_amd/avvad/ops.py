@@ -23,7 +23,7 @@ def side_stream():
     dev = torch.cuda.current_device()
     if dev not in _SIDE:
         import os
-        _SIDE[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("AVVAD_SIDE_PRIO", "0")))
+        _SIDE[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("AVVAD_SIDE_PRIO", "-1")))
     return _SIDE[dev]
 
 
