@@ -194,7 +194,7 @@ struct Stage {
 template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi>
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 128) ? 2 : 3))
     kernel(const AOp A, const BOp B, const Epi E, const int M, const int N, const int K, const int ktiles,
-           const int full_rounds, const int rem_tiles) {
+           const int full_rounds, const int rem_tiles, const int kchunks) {
   typedef Stage<AOp, BM, NTH> SA;
   typedef Stage<BOp, BN, NTH> SB;
   constexpr int WGN = NTH / 128;                  // waves along N (2 or 4); 2 along M
@@ -215,10 +215,23 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
   const long it_end = (g + 1) * rem_iters / G;
   const long ntiles_all = (long)((M + BM - 1) / BM) * ntn;
   int round = 0;
+  long cell = g;   // K-major mode (kchunks > 0): cell = chunk * ntiles + tile, workers take cells g, g+G, ...
 
   for (;;) {
     int tile, kt0, kt1;
-    if (round < full_rounds) {                       // data-parallel rounds: whole tiles
+    if (kchunks > 0) {
+      // K-MAJOR CELLS (few tiles, long K: the conv weight gradients).  K is cut into kchunks ranges and the cells
+      // (range, tile) are dealt out tile-fastest, so neighbouring workers -- one XCD after the remap -- contract the
+      // SAME pixel range for different output tiles and share its dy / x lines in L2.  Tile-major stream-K gave every
+      // XCD its own private walk over all pixels: the wgrad kernel fetched 460 MB per launch from beyond L2.
+      if (cell >= (long)kchunks * ntiles_all) break;
+      const int c = (int)(cell / ntiles_all);
+      tile = (int)(cell - (long)c * ntiles_all);
+      kt0 = (int)((long)c * ktiles / kchunks);
+      kt1 = (int)((long)(c + 1) * ktiles / kchunks);
+      cell += G;
+      if (kt1 <= kt0) continue;
+    } else if (round < full_rounds) {                       // data-parallel rounds: whole tiles
       const long tl = (long)round * G + g;
       ++round;
       if (tl >= ntiles_all) continue;                // last, partially filled round
@@ -407,12 +420,13 @@ static __global__ void zero_strided(float* C, int M, int N, long ldc, int cs) {
 
 constexpr int NUM_CU = 256;  // MI355X
 
-// split_k_hint is kept for API symmetry; the scheduler decides the decomposition.
+// split_k_hint > 1 marks a "few tiles, very long K" product whose partial tiles are atomically accumulated by the
+// epilogue (the conv weight gradients): it is cut K-major (see the kernel); everything else is scheduled as
+// data-parallel rounds + one stream-K round.
 template <int BM, int BN, class AOp, class BOp, class Epi>
 static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N, int K, int split_k_hint,
                          hipStream_t s) {
   if (M <= 0 || N <= 0 || K <= 0) return AVVAD_EINVAL;
-  (void)split_k_hint;
   const int ktiles = (K + BK - 1) / BK;
   const long ntiles = (long)cdiv(M, BM) * cdiv(N, BN);
   const long iters = ntiles * ktiles;
@@ -428,35 +442,54 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   const char* nsk = getenv("AVVAD_NO_STREAMK");   // debugging aid: "all", or the epilogue mode digit to restrict
   const bool no_sk = nsk && (nsk[0] == 'a' || nsk[0] - '0' == e.mode);
   long full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
-  if (no_sk || rem * 10 >= G * 9) {   // (nearly) full last round: keep it data-parallel
-    if (rem > 0) ++full_rounds;
-    rem = 0;
-  }
-  if (rem > 0) {
-    if (full_rounds == 0) {           // fewer tiles than workers: >= 4 iterations per worker amortise prologue/epilogue
-      const long cap = iters / 4 > 0 ? iters / 4 : 1;
-      if (G > cap) G = cap;
+  int kchunks = 0;
+  // OFF by default (AVVAD_KMAJOR=1 turns it on): it removes most of the wgrad kernel's beyond-L2 fetches, but the
+  // kernels are MFMA-bound -- isolated they time the same (+-2 %), and the whole training step measured 0.45 ms
+  // (2 %) SLOWER in three A/B/A/B pairs on one device (23.7 vs 23.25 ms), so tile-major stream-K stays the default.
+  if (split_k_hint > 1 && e.mode == 2 && ntiles <= G && getenv("AVVAD_KMAJOR")) {
+    // r cells per worker (r = 1 or 2): kchunks = floor(r*G / ntiles); cost in K-tile iterations incl. ~8 per atomic flush
+    long best = -1;
+    for (int r = 1; r <= 2; ++r) {
+      long nc = r * G / ntiles;
+      if (nc > ktiles) nc = ktiles;
+      if (nc < 1) nc = 1;
+      const long rr = (nc * ntiles + G - 1) / G;
+      const long cost = rr * ((ktiles + nc - 1) / nc) + rr * 8;
+      if (best < 0 || cost < best) { best = cost; kchunks = (int)nc; }
     }
-    // (AVVAD_SKIP_ZERO: timing aid for bench.py's roofline probe, which wants the GEMM kernel's own duration --
-    // the zero-fill is a separate kernel with its own line in the rocprof summary; results are garbage with it set)
-    if (e.mode == 0 && !getenv("AVVAD_SKIP_ZERO")) {  // split pieces are atomically added: their tiles must start at zero
-      // only the stream-K round's tiles (the last `rem`, in row-major tile order) are added to; the tile rows from the
-      // first of them down cover them -- the data-parallel tiles caught in that band are overwritten by plain stores
-      const long row0 = (full_rounds * G / cdiv(N, BN)) * BM;
-      const long n = (long)(M - row0) * N;
-      if (n > 0)
-        hipLaunchKernelGGL(zero_strided, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,
-                           e.C + row0 * e.ldc, (int)(M - row0), N, e.ldc, e.cs);
+    full_rounds = 0; rem = 0;
+    if ((long)kchunks * ntiles < G) G = (long)kchunks * ntiles;
+  } else {
+    if (no_sk || rem * 10 >= G * 9) {   // (nearly) full last round: keep it data-parallel
+      if (rem > 0) ++full_rounds;
+      rem = 0;
+    }
+    if (rem > 0) {
+      if (full_rounds == 0) {           // fewer tiles than workers: >= 4 iterations per worker amortise prologue/epilogue
+        const long cap = iters / 4 > 0 ? iters / 4 : 1;
+        if (G > cap) G = cap;
+      }
+      // (AVVAD_SKIP_ZERO: timing aid for bench.py's roofline probe, which wants the GEMM kernel's own duration --
+      // the zero-fill is a separate kernel with its own line in the rocprof summary; results are garbage with it set)
+      if (e.mode == 0 && !getenv("AVVAD_SKIP_ZERO")) {  // split pieces are atomically added: their tiles must start at zero
+        // only the stream-K round's tiles (the last `rem`, in row-major tile order) are added to; the tile rows from the
+        // first of them down cover them -- the data-parallel tiles caught in that band are overwritten by plain stores
+        const long row0 = (full_rounds * G / cdiv(N, BN)) * BM;
+        const long n = (long)(M - row0) * N;
+        if (n > 0)
+          hipLaunchKernelGGL(zero_strided, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,
+                             e.C + row0 * e.ldc, (int)(M - row0), N, e.ldc, e.cs);
+      }
     }
   }
   const int fr = (int)full_rounds, rt = (int)rem;
   if (variant == 0)
-    hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt);
+    hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
   else if (variant == 1 || !BIG)
-    hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt);
+    hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
   else
     hipLaunchKernelGGL((kernel<BM, BN, true, (BIG ? 512 : 256), AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K,
-                       ktiles, fr, rt);
+                       ktiles, fr, rt, kchunks);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }
