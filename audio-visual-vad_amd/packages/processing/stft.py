@@ -15,9 +15,26 @@ def stft_pytorch(x, fs=16e3, wlen_sec=50e-3, win='hann', hop_percent=0.25, cente
         raise ValueError("wlen_sample of STFT is not an integer.")
     nfft = int(wlen_sec * fs)
     hopsamp = int(hop_percent * nfft)
-    if x.is_cuda and not center and isinstance(win, str) and win == 'hann' and nfft % 32 == 0:
-        from avvad import ops                      # GPU: framing + Hann + DFT as one MFMA GEMM (csrc/stft.hip)
-        return ops.stft(x, nfft, hopsamp, mode=2, pad_at_end=pad_at_end, fs=fs)
+    if x.is_cuda:
+        # GPU tensors ALWAYS take the HIP front-end (framing + Hann + DFT as one MFMA GEMM, csrc/stft.hip); a
+        # configuration it does not implement is an error, never a silent library call.  center=True is the
+        # reference's reflect padding of nfft/2 samples per side, applied (after its end padding) as plain data movement.
+        from avvad import ops
+        from avvad._lib import AvvadError
+        if not (isinstance(win, str) and win == 'hann'):
+            raise AvvadError("GPU stft_pytorch implements the reference's periodic Hann window only")
+        if nfft % 32:
+            raise AvvadError("GPU stft_pytorch needs an FFT length that is a multiple of 32 (got %d)" % nfft)
+        if not center:
+            return ops.stft(x, nfft, hopsamp, mode=2, pad_at_end=pad_at_end, fs=fs)
+        x_ = x
+        if pad_at_end:
+            n_hops = len(x) / fs / wlen_sec / hop_percent
+            if math.ceil(n_hops) != int(n_hops):
+                x_ = torch.nn.functional.pad(x, (0, hopsamp), mode='constant')
+        x_ = torch.nn.functional.pad(x_.view(1, 1, -1), (nfft // 2, nfft // 2), mode=pad_mode).view(-1)
+        return ops.stft(x_, nfft, hopsamp, mode=2, pad_at_end=False, fs=fs)
+    # host tensors: the reference's own call (a torch.stft wrapper run by its CPU data pipeline), kept for data prep
     x_ = x
     if pad_at_end:
         n_hops = len(x) / fs / wlen_sec / hop_percent

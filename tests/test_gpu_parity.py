@@ -473,6 +473,14 @@ def test_stft_frontend_gpu(L):
     lp = log_power_spectrogram(xb.to(DEV))
     pw_ref = torch.stack([(frontend.stft(r, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, center=False) ** 2).sum(-1).t() for r in xb])
     _report("stft power L=%d" % L, torch.exp(lp) - 1e-8, pw_ref, 2e-3, 1e-4)
+    # the reference's default center=True (reflect padding), same kernel behind it
+    ref_c = frontend.stft(x, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, center=True, pad_at_end=True)
+    S_c = stft_pytorch(x.to(DEV), fs=16e3, wlen_sec=64e-3, win='hann', hop_percent=0.25, center=True, pad_at_end=True)
+    assert tuple(S_c.shape) == tuple(ref_c.shape)
+    _report("stft centred re/im L=%d" % L, S_c, ref_c, 5e-4)
+    from avvad import AvvadError
+    with pytest.raises(AvvadError):      # no silent library fallback for what the kernel does not implement
+        stft_pytorch(x.to(DEV), fs=16e3, wlen_sec=64e-3, win=torch.ones(1024, device=DEV), center=False)
 
 
 # ------------------------------------------------------------------------------------------ BASELINE-size properties
