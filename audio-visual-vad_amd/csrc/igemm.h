@@ -119,7 +119,9 @@ struct ColPlain {
 
 #ifdef AVVAD_PROF
 // tuning aid (never in the shipped build): per-phase shader-clock totals of wave 0 of every workgroup
-__device__ unsigned long long g_prof[8];   // 0 segments, 1 prologue, 2 loop, 3 barrier wait, 4 staging, 5 epilogue, 6 ktile iterations
+__device__ unsigned long long g_prof[8];
+__device__ unsigned long long g_prof_blk[2 * 2048];   // per block: s_memrealtime (100 MHz) at start / end of the LAST launch
+__device__ unsigned long long g_prof_hw[2048];        // per block: XCC_ID << 32 | HW_ID (which CU / wave slot it landed on)   // 0 segments, 1 prologue, 2 loop, 3 barrier wait, 4 staging, 5 epilogue, 6 ktile iterations
 #define PROF_T() ((wave == 0) ? __builtin_amdgcn_s_memtime() : 0ull)
 #define PROF_ADD(i, v) do { if (t == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
 #else
@@ -189,10 +191,20 @@ struct Stage {
 // equal contiguous shares: a tile may be split between workers, and split pieces are added with float atomics onto
 // a pre-zeroed (or accumulating) output.  That removes the tile-quantisation loss of e.g. 648 or 288 tiles on 512
 // resident slots (37 % / 44 % idle) while only the last round pays the ~1.3 TB/s float-atomic rate.
+// Measured balance of this static split (tools/lab/prof_conv.py, -DAVVAD_PROF): all G workers start within 0.5 us; the
+// two workgroups of a CU are raw block ids b and b+256 and the OLDER always finishes first (192 vs 237 us: the matrix
+// pipe is arbitrated oldest-first); XCDs finish up to 17 % apart on equal shares (the same two are slowest for every
+// shape on a given device).  Tried and dropped: age-skewed shares (+-1 %), a dynamically pulled tail pool of 8-K-tile
+// pieces (1-5 % slower: every piece pays a prologue and a 64 KB atomic flush), K-major cells for the weight gradients
+// (less HBM traffic, 2 % slower end to end), staggering the co-residents' phases (no effect).
 // NTH = 256: 4 waves as 2x2, each (BM/2)x(BN/2);  NTH = 512: 8 waves as 2x4, each (BM/2)x(BN/4) -- half the
 // accumulators and staging registers per wave, so twice the waves per SIMD fit next to the same LDS tile.
 template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi>
-__global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 128) ? 2 : 3))
+// (HIP's second launch-bounds argument is WAVES PER SIMD, not blocks per CU.  The 8-wave instantiation is pinned to
+//  4 waves/SIMD = the 2 workgroups/CU launch() assumes: a build drifting past 128 VGPRs would otherwise silently halve
+//  the residency -- the instrumented -DAVVAD_PROF build did exactly that.  The 4-wave instantiations are left looser:
+//  pinning them to their per_cu made the 64x64 kernels spill.)
+__global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 128) ? 2 : 3))
     kernel(const AOp A, const BOp B, const Epi E, const int M, const int N, const int K, const int ktiles,
            const int full_rounds, const int rem_tiles, const int kchunks) {
   typedef Stage<AOp, BM, NTH> SA;
@@ -208,6 +220,13 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
   const int wm = wave / WGN, wn = wave % WGN;
   const int ntn = (N + BN - 1) / BN;
 
+#ifdef AVVAD_PROF
+  if (t == 0 && blockIdx.x < 2048) {
+    g_prof_blk[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    g_prof_hw[blockIdx.x] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) |
+                            (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+  }
+#endif
   const long G = gridDim.x;
   const long g = xcd_remap(blockIdx.x, gridDim.x);
   const long rem_iters = (long)rem_tiles * ktiles;
@@ -410,6 +429,9 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 2 : ((DB || BM * BN < 128 * 
     PROF_ADD(6, kt1 - kt0);
 #endif
   }
+#ifdef AVVAD_PROF
+  if (t == 0 && blockIdx.x < 2048) g_prof_blk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 static __global__ void zero_strided(float* C, int M, int N, long ldc, int cs) {

@@ -399,6 +399,14 @@ extern "C" int avvad_debug_prof(unsigned long long* out, int reset) {
   if (reset) { unsigned long long z[8] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(igemm::g_prof), z, sizeof(z)); }
   return 0;
 }
+extern "C" int avvad_debug_prof_blocks(unsigned long long* out, int n) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(igemm::g_prof_blk), sizeof(unsigned long long) * 2 * n);
+  return 0;
+}
+extern "C" int avvad_debug_prof_hw(unsigned long long* out, int n) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(igemm::g_prof_hw), sizeof(unsigned long long) * n);
+  return 0;
+}
 #endif
 extern "C" int avvad_conv2d_dgrad(const float* dy, const float* wd, float* dx, const avvad_conv_desc* d, int accumulate,
                                   avvad_stream_t s) {

@@ -292,6 +292,97 @@ __global__ void __launch_bounds__(512, 2) v0c(const float* __restrict__ At, cons
   }
 }
 
+// ---- v2: 256x128 tile, 8 waves as 4x2, each 64x64 (4 accumulators), double-buffered LDS (101 KB -> 1 workgroup / CU)
+template <int PERSIST>
+__global__ void __launch_bounds__(512, 1) v2(const float* __restrict__ At, const float* __restrict__ B, float* __restrict__ C, int M, int N, int K,
+                                              unsigned long long* clk) {
+  constexpr int BM = 256, BN = 128, LDA = 260, LDB = 132;
+  constexpr int TILE = BK * LDA + BK * LDB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, li = lane & 31, lh = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ntn = N / BN;
+  const int ntiles = (M / BM) * ntn;
+  const int ktiles = K / BK;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  const int xa = (t & 63) * 4, ka0 = t >> 6;    // A: 64 float4 per k-row, 8 rows per pass, 4 passes
+  const int xb = (t & 31) * 4, kb0 = t >> 5;    // B: 32 float4 per k-row, 16 rows per pass, 2 passes
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = (tile / ntn) * BM, n0 = (tile % ntn) * BN;
+    float sa[4][4], sb[2][4];
+    auto gload = [&](int kt) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 ta = *reinterpret_cast<const float4*>(At + (long)(kt * BK + ka0 + 8 * i) * M + m0 + xa);
+        sa[i][0] = ta.x; sa[i][1] = ta.y; sa[i][2] = ta.z; sa[i][3] = ta.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 tb = *reinterpret_cast<const float4*>(B + (long)(kt * BK + kb0 + 16 * i) * N + n0 + xb);
+        sb[i][0] = tb.x; sb[i][1] = tb.y; sb[i][2] = tb.z; sb[i][3] = tb.w;
+      }
+    };
+    auto to_lds = [&](float* S) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(S + (ka0 + 8 * i) * LDA + xa) = make_float4(sa[i][0], sa[i][1], sa[i][2], sa[i][3]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i) *reinterpret_cast<float4*>(S + BK * LDA + (kb0 + 16 * i) * LDB + xb) = make_float4(sb[i][0], sb[i][1], sb[i][2], sb[i][3]);
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    gload(0);
+    __syncthreads();
+    to_lds(smem);
+    gload(1);
+    __syncthreads();
+    for (int kt = 0; kt < ktiles; ++kt) {
+      const int cur = kt & 1;
+      float* As = smem + cur * TILE;
+      float* Bs = As + BK * LDA;
+      const float* ap = As + lh * LDA + wm * 64 + li;
+      const float* bp = Bs + lh * LDB + wn * 64 + li;
+      float a[2][2], b[2][2];
+      a[0][0] = ap[0]; a[0][1] = ap[32]; b[0][0] = bp[0]; b[0][1] = bp[32];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        if (ks == 8 && kt + 1 < ktiles) {
+          float* An = smem + (cur ^ 1) * TILE;
+          to_lds(An);
+          if (kt + 2 < ktiles) gload(kt + 2);
+        }
+        if (ks + 1 < 16) {
+          a[(ks + 1) & 1][0] = ap[(ks + 1) * 2 * LDA];
+          a[(ks + 1) & 1][1] = ap[(ks + 1) * 2 * LDA + 32];
+          b[(ks + 1) & 1][0] = bp[(ks + 1) * 2 * LDB];
+          b[(ks + 1) & 1][1] = bp[(ks + 1) * 2 * LDB + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = mfma32(a[ks & 1][0], b[ks & 1][0], acc[0][0]);
+        acc[0][1] = mfma32(a[ks & 1][0], b[ks & 1][1], acc[0][1]);
+        acc[1][0] = mfma32(a[ks & 1][1], b[ks & 1][0], acc[1][0]);
+        acc[1][1] = mfma32(a[ks & 1][1], b[ks & 1][1], acc[1][1]);
+      }
+      __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + wn * 64 + j * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) C[(long)(m0 + wm * 64 + i * 32 + mfma32_row(r, lh)) * N + n] = acc[i][j][r];
+      }
+    if (!PERSIST) break;
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (t == 0 && clk && blockIdx.x < 1024) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
 static unsigned long long* dClk;
 static void report_clock(const char* name, int tiles) {
   std::vector<unsigned long long> h(2 * tiles);
@@ -324,6 +415,10 @@ static void run_variants() {
   CK(hipMalloc(&dClk, sizeof(unsigned long long) * 2 * tiles));
   SUSTAIN("v0c 32x32x2 full", hipLaunchKernelGGL(v0c<0>, dim3(tiles), dim3(512), 0, 0, dA, dB, dC, M, N, K, dClk));
   check("v0c");
+  { const int tiles = 256; SUSTAIN("v2 256x128 persistent 256wg", hipLaunchKernelGGL(v2<1>, dim3(256), dim3(512), 0, 0, dA, dB, dC, M, N, K, dClk)); }
+  check("v2p");
+  { const int tiles = 512; SUSTAIN("v2 256x128 512 blocks", hipLaunchKernelGGL(v2<0>, dim3(512), dim3(512), 0, 0, dA, dB, dC, M, N, K, dClk)); }
+  check("v2");
   SUSTAIN("v16 16x16x4 full", hipLaunchKernelGGL(v16<0>, dim3(tiles), dim3(512), 0, 0, dA, dB, dC, M, N, K, dClk));
   check("v16");
   SUSTAIN("v0c 32x32x2 mfma-only", hipLaunchKernelGGL(v0c<8>, dim3(tiles), dim3(512), 0, 0, dA, dB, dC, M, N, K, dClk));
