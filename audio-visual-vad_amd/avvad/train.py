@@ -169,5 +169,24 @@ def evaluate_main(kind, make_model, checkpoint=None, waveform=False, n_items=16,
             soft = torch.sigmoid(logits[0])
             torch.save(soft.cpu(), os.path.join(out_dir, "utt%04d_y_hat_soft.pt" % i))
             torch.save((soft > 0.5).int().cpu(), os.path.join(out_dir, "utt%04d_y_hat_hard.pt" % i))
+            torch.save(y[0].int().cpu(), os.path.join(out_dir, "utt%04d_label.pt" % i))   # synthetic stand-in for the dataset's labels
     if rank == 0:
         print("Finished in {:.2f} seconds".format(time.perf_counter() - t0))
+
+
+def metrics_main(out_dir="eval_out", confidence=0.95, eps=1e-8):
+    """The body of ``scripts/run_metrics_dnn_classif.py`` (``:102-300``) for the classifier outputs: per utterance
+    ``f1_loss(y_hat_hard, y)`` -> (accuracy, precision, recall, F1), then ``compute_stats`` tables with Student-t
+    confidence intervals.  Reads the ``*_y_hat_hard.pt`` / ``*_label.pt`` pairs that ``evaluate_main`` wrote."""
+    import glob
+    from packages.metrics import compute_stats
+    from packages.models.utils import f1_loss
+    rows = []
+    for hard_path in sorted(glob.glob(os.path.join(out_dir, "*_y_hat_hard.pt"))):
+        y_hat = torch.load(hard_path, weights_only=True).reshape(-1)
+        y = torch.load(hard_path.replace("_y_hat_hard.pt", "_label.pt"), weights_only=True).reshape(-1)
+        rows.append(tuple(float(v) for v in f1_loss(y_hat, y.long(), eps)))
+    if len(rows) < 2:
+        raise SystemExit("need at least two evaluated utterances in %s (run scripts/evaluate_*_net.py first)" % out_dir)
+    return compute_stats(metrics_keys=["accuracy", "precision", "recall", "f1score"], all_metrics=rows, model_data_dir=out_dir,
+                         confidence=confidence)

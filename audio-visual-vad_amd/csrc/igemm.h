@@ -121,6 +121,7 @@ struct ColPlain {
 // tuning aid (never in the shipped build): per-phase shader-clock totals of wave 0 of every workgroup
 __device__ unsigned long long g_prof[8];
 __device__ unsigned long long g_prof_blk[2 * 2048];   // per block: s_memrealtime (100 MHz) at start / end of the LAST launch
+__device__ unsigned long long g_prof_clk[2048];       // per block: shader cycles (s_memtime) spent in the kernel
 __device__ unsigned long long g_prof_hw[2048];        // per block: XCC_ID << 32 | HW_ID (which CU / wave slot it landed on)   // 0 segments, 1 prologue, 2 loop, 3 barrier wait, 4 staging, 5 epilogue, 6 ktile iterations
 #define PROF_T() ((wave == 0) ? __builtin_amdgcn_s_memtime() : 0ull)
 #define PROF_ADD(i, v) do { if (t == 0) atomicAdd(&g_prof[i], (unsigned long long)(v)); } while (0)
@@ -223,6 +224,7 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
 #ifdef AVVAD_PROF
   if (t == 0 && blockIdx.x < 2048) {
     g_prof_blk[2 * blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    g_prof_clk[blockIdx.x] = __builtin_amdgcn_s_memtime();
     g_prof_hw[blockIdx.x] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) |
                             (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
   }
@@ -430,7 +432,10 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
 #endif
   }
 #ifdef AVVAD_PROF
-  if (t == 0 && blockIdx.x < 2048) g_prof_blk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+  if (t == 0 && blockIdx.x < 2048) {
+    g_prof_blk[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+    g_prof_clk[blockIdx.x] = __builtin_amdgcn_s_memtime() - g_prof_clk[blockIdx.x];
+  }
 #endif
 }
 

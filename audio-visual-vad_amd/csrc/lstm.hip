@@ -10,6 +10,7 @@
 // pre-activations) + one fused gate kernel.  The activated gates overwrite the
 // pre-activations in the workspace and are what backward consumes.
 #include "gemm_api.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -35,6 +36,77 @@ __global__ void lstm_gates_fwd(float* __restrict__ G, float* __restrict__ Cs, fl
   }
   const float ig = sigmoidf_(g[j]), fg = sigmoidf_(g[H + j]), gg = tanhf(g[2 * H + j]), og = sigmoidf_(g[3 * H + j]);
   const float cp = t > 0 ? Cs[o - H] : 0.f;
+  const float c = fg * cp + ig * gg;
+  g[j] = ig; g[H + j] = fg; g[2 * H + j] = gg; g[3 * H + j] = og;
+  Cs[o] = c;
+  y[o] = og * tanhf(c);
+}
+
+// ------------------------------------------------------------------ fused recurrent step (t >= 1), B % 16 == 0, H % 16 == 0
+// One launch does what the stream-K GEMM (M = B rows only: 64 x 4096 x 1024, atomics onto the pre-activations) plus
+// lstm_gates_fwd did in two.  Workgroup blk owns hidden units 4*blk .. 4*blk+3, i.e. the 16 gate rows
+// {gate*H + 4*blk + u}; wave w owns sequences 16w .. 16w+15.  v_mfma_f32_16x16x4_f32 with D[16 gate rows][16 sequences]:
+// lane (i = l&15, q = l>>4) feeds A = W_hh[row(i)][k] and B = h_{t-1}[b][k]; both are read as float4 along k straight
+// from L2 (no LDS: nothing is shared between waves but the 64 KB weight slab, which L1 serves) and the 4 elements go to 4
+// MFMAs -- the k-slot q of MFMA e stands for k = 16*kk + 4*q + e on both operands, a permutation of the contraction
+// order only.  Row order 4*u + gate puts the four gate sums of unit q in the four accumulator registers of lane (b, q),
+// so the gate arithmetic (identical to lstm_gates_fwd) runs in registers.
+// The workgroup always runs 16 waves: B/16 sequence blocks x KS = 16/(B/16) K-slices (the loads are L2-latency-bound, so
+// a wave keeps 16 float4 loads in flight over a short slice instead of walking all of K); the slices' partial sums meet
+// in LDS and the slice-0 waves finish the step.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(1024)
+    lstm_step_fwd_mfma(float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ y, const float* __restrict__ w_hh,
+                       const int* __restrict__ lengths, int B, int T, int H, int t) {
+  __shared__ f32x4v part[16][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nb = B >> 4, KS = 16 / nb;
+  const int wb = wave % nb, ks = wave / nb;
+  const int i = lane & 15, q = lane >> 4;
+  const int blk = blockIdx.x;
+  const int b = wb * 16 + i;                                 // this lane's sequence (B operand column / D column)
+  const int kspan = H / KS;                                  // host guarantees H % (16*KS) == 0
+  const float* wrow = w_hh + (long)((i & 3) * H + 4 * blk + (i >> 2)) * H + ks * kspan + 4 * q;   // A row i = 4*u + gate
+  const float* hrow = y + ((long)b * T + (t - 1)) * H + ks * kspan + 4 * q;
+  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  const int nk = kspan >> 4;
+  for (int k0 = 0; k0 < nk; k0 += 8) {
+    float4 a[8], h[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int kk = (k0 + u < nk) ? k0 + u : nk - 1;       // clamped (nk % 8 != 0 shapes); masked below
+      a[u] = *reinterpret_cast<const float4*>(wrow + 16 * kk);
+      h[u] = *reinterpret_cast<const float4*>(hrow + 16 * kk);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (k0 + u < nk) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, h[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, h[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, h[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, h[u].w, acc, 0, 0, 0);
+      }
+    }
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (ks != 0) return;
+  for (int s2 = 1; s2 < KS; ++s2) {
+    const f32x4v p = part[s2 * nb + wb][lane];
+    acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+  }
+  // acc[r] = recurrent part of gate r of unit 4*blk + q for sequence b
+  const int j = 4 * blk + q;
+  float* g = G + ((long)b * T + t) * 4 * H;
+  const long o = ((long)b * T + t) * H + j;
+  if (t >= lengths[b]) {
+    g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f; g[3 * H + j] = 0.f;
+    Cs[o] = 0.f; y[o] = 0.f;
+    return;
+  }
+  const float ig = sigmoidf_(g[j] + acc[0]), fg = sigmoidf_(g[H + j] + acc[1]), gg = tanhf(g[2 * H + j] + acc[2]),
+              og = sigmoidf_(g[3 * H + j] + acc[3]);
+  const float cp = Cs[o - H];
   const float c = fg * cp + ig * gg;
   g[j] = ig; g[H + j] = fg; g[2 * H + j] = gg; g[3 * H + j] = og;
   Cs[o] = c;
@@ -150,7 +222,13 @@ extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const flo
   avvad_gemm_desc gd = gemm_desc(B * T, 4 * H, In, In, In, 4 * H, 0, 1, 0, 1);
   if ((rc = avvad_gemm_impl(x, w_ih, w.bias, w.G, &gd, s))) return rc;
   const int split = pick_split(B, 4 * H, H);
+  const bool fused_step = (B == 16 || B == 32 || B == 64 || B == 128 || B == 256) && (H % (16 * (256 / B)) == 0) &&
+                          !getenv("AVVAD_LSTM_NO_FUSED_STEP");
   for (int t = 0; t < T; ++t) {
+    if (t > 0 && fused_step) {
+      hipLaunchKernelGGL(lstm_step_fwd_mfma, dim3(H / 4), dim3(1024), 0, s, w.G, w.Cs, y, w_hh, d->lengths, B, T, H, t);
+      continue;
+    }
     if (t > 0) {
       avvad_gemm_desc rd = gemm_desc(B, 4 * H, H, T * H, H, T * 4 * H, 0, 1, 1, split);
       if ((rc = avvad_gemm_impl(y + (long)(t - 1) * H, w_hh, nullptr, w.G + (long)t * 4 * H, &rd, s))) return rc;

@@ -403,6 +403,10 @@ extern "C" int avvad_debug_prof_blocks(unsigned long long* out, int n) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(igemm::g_prof_blk), sizeof(unsigned long long) * 2 * n);
   return 0;
 }
+extern "C" int avvad_debug_prof_clk(unsigned long long* out, int n) {
+  hipMemcpyFromSymbol(out, HIP_SYMBOL(igemm::g_prof_clk), sizeof(unsigned long long) * n);
+  return 0;
+}
 extern "C" int avvad_debug_prof_hw(unsigned long long* out, int n) {
   hipMemcpyFromSymbol(out, HIP_SYMBOL(igemm::g_prof_hw), sizeof(unsigned long long) * n);
   return 0;

@@ -409,9 +409,13 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     assert "Number of learnable parameters" in log and "====> Epoch:  1" in log
     T.evaluate_main("av", make, checkpoint=str(tmp_path / "m" / ck[0]), waveform=True, n_items=3, out_dir=str(tmp_path / "e"))
     outs = sorted(os.listdir(tmp_path / "e"))
-    assert outs == ["utt%04d_y_hat_%s.pt" % (i, k) for i in range(3) for k in ("hard", "soft")]
+    assert outs == sorted(["utt%04d_%s.pt" % (i, k) for i in range(3) for k in ("y_hat_hard", "y_hat_soft", "label")])
     soft = torch.load(tmp_path / "e" / "utt0000_y_hat_soft.pt", weights_only=True)
     assert soft.shape == (16, 1) and float(soft.min()) >= 0 and float(soft.max()) <= 1
+    # run_metrics: per-utterance accuracy / precision / recall / F1 -> mean +- Student-t half-width
+    stats = T.metrics_main(str(tmp_path / "e"))
+    assert set(stats["all"]) == {"accuracy", "precision", "recall", "f1score"}
+    assert 0.0 <= stats["all"]["accuracy"]["avg"] <= 1.0
 
 
 def test_training_steps_match_cpu_adam():

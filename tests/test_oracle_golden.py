@@ -173,3 +173,18 @@ def test_stft_vs_naive_dft(L):
         assert S.shape[1] == 60 and padded          # 1 s chunk <-> 60 frames
     np.testing.assert_allclose(S[..., 0].numpy(), ref.real, atol=2e-4)
     np.testing.assert_allclose(S[..., 1].numpy(), ref.imag, atol=2e-4)
+
+
+def test_metrics_tables_match_reference(capsys):
+    """packages.metrics against outputs of the reference's own functions: Student-t confidence
+    intervals and the printed METRIC / AVERAGE / CONF. INT. tables (overall + per input SNR)."""
+    from packages import metrics
+    g = load_golden("metrics")
+    per_utt = g["per_utt"]
+    got = np.array([metrics.mean_confidence_interval(per_utt[:, j], confidence=c) for j in range(4) for c in (0.95, 0.9)])
+    np.testing.assert_array_equal(got, g["ci"])
+    capsys.readouterr()
+    stats = metrics.compute_stats(metrics_keys=["accuracy", "precision", "recall", "f1score"],
+                                  all_metrics=[tuple(r) for r in per_utt], model_data_dir="", confidence=0.95, all_snr_db=g["snr"])
+    assert capsys.readouterr().out == bytes(g["table"]).decode()
+    assert stats["all"]["f1score"]["avg"] == g["ci"][6][0]

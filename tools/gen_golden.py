@@ -244,7 +244,26 @@ def gen_misc():
          av=np.array(ref_utils.count_parameters(DeepVAD_AV(2, 1024, 1))))
 
 
+# ------------------------------------------------------------------ reporting: confidence intervals / stats tables
+def gen_metrics():
+    import contextlib
+    import io
+    from packages import metrics as ref_metrics
+    rng = np.random.RandomState(77)
+    per_utt = rng.rand(24, 4)                                   # accuracy, precision, recall, f1 per utterance
+    snr = np.array([-5, 0, 5, 10] * 6, dtype=np.float64)
+    noise = np.array((["Babble"] * 8) + (["Cafe"] * 8) + (["Car"] * 8))
+    keys = ["accuracy", "precision", "recall", "f1score"]
+    ci = np.array([ref_metrics.mean_confidence_interval(per_utt[:, j], confidence=c) for j in range(4) for c in (0.95, 0.9)])
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        ref_metrics.compute_stats(metrics_keys=keys, all_metrics=[tuple(r) for r in per_utt], model_data_dir="", confidence=0.95,
+                                  all_snr_db=snr)
+    text = buf.getvalue()
+    save("metrics", per_utt=per_utt, snr=snr, noise=noise, ci=ci, table=np.frombuffer(text.encode(), dtype=np.uint8))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["wavenet", "audio", "video", "av", "misc"]
+    which = sys.argv[1:] or ["wavenet", "audio", "video", "av", "misc", "metrics"]
     for w in which:
         globals()["gen_" + w]()

@@ -52,6 +52,14 @@ def run(what, *a):
     for b in range(nb): cu_end[int(key[b])] = max(cu_end.get(int(key[b]), 0.0), float(en[b]))
     byx = {}
     for k_, e_ in cu_end.items(): byx.setdefault(k_ // 10000, []).append(e_)
+    ck = (C.c_ulonglong * nb)()
+    lib.avvad_debug_prof_clk.argtypes = [C.c_void_p, C.c_int]
+    lib.avvad_debug_prof_clk(ck, nb)
+    cyc = np.array(list(ck), dtype=np.float64)
+    ghz = cyc / (d * 1e3)              # cycles / (us * 1000) = GHz
+    byc = {}
+    for b in range(nb): byc.setdefault(int(xcc[b]), []).append(ghz[b])
+    print("   in-kernel clock by XCD (GHz): " + "  ".join("x%d %.3f" % (x_, sum(v_) / len(v_)) for x_, v_ in sorted(byc.items())))
     print("   CU finish time by XCD (min/mean/max): " + "  ".join("x%d %.0f/%.0f/%.0f" % (x_, min(v_), sum(v_) / len(v_), max(v_)) for x_, v_ in sorted(byx.items())))
     print("   last launch, 512 workers (us): start spread %.1f | end min %.1f median %.1f max %.1f | busy min %.1f median %.1f max %.1f"
           % (st.max(), en.min(), np.median(en), en.max(), d.min(), np.median(d), d.max()), flush=True)
