@@ -20,6 +20,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # Rehearsal aids for a one-GPU box (RCCL refuses two ranks on one device): AVVAD_DIST_BACKEND=gloo moves the
+    # all-reduce through the host, AVVAD_FORCE_DEVICE=0 puts every rank on that device.  Never set in production.
+    backend = os.environ.get("AVVAD_DIST_BACKEND", backend)
+    if "AVVAD_FORCE_DEVICE" in os.environ:
+        local = int(os.environ["AVVAD_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
