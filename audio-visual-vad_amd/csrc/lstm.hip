@@ -54,6 +54,9 @@ __global__ void lstm_gates_fwd(float* __restrict__ G, float* __restrict__ Cs, fl
 // The workgroup always runs 16 waves: B/16 sequence blocks x KS = 16/(B/16) K-slices (the loads are L2-latency-bound, so
 // a wave keeps 16 float4 loads in flight over a short slice instead of walking all of K); the slices' partial sums meet
 // in LDS and the slice-0 waves finish the step.
+// (Tried: ONE persistent launch per layer with the W_hh fragments resident in registers and a grid barrier per step --
+//  correct, but 0.4 ms/step SLOWER end to end: the per-step release/acquire fences that carry h_t across XCDs write back
+//  and invalidate the whole L2, which costs more than re-streaming W_hh from the Infinity Cache.)
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(1024)
     lstm_step_fwd_mfma(float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ y, const float* __restrict__ w_hh,
