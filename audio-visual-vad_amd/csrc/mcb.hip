@@ -146,8 +146,9 @@ struct Chunks { int n; long per; };
 static Chunks chunks(long M, int C) {
   const int RL = 256 / (C / 4) > 0 ? 256 / (C / 4) : 1;
   long per = (M + STAT_CHUNKS - 1) / STAT_CHUNKS;
+  if (per < 16L * RL) per = 16L * RL;   // >= 16 rows per thread: fewer, fuller chunks for the small deep layers (the finalize
+                                         // kernels read every chunk's partial sums)
   per = (per + RL - 1) / RL * RL;
-  if (per < RL) per = RL;
   Chunks c;
   c.per = per;
   c.n = cdiv(M, per);

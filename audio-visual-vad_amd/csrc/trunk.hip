@@ -322,8 +322,9 @@ static StatCtx stat_ctx(Plan* p, float* ws, long M, int C) {
   c.part = reinterpret_cast<double*>(ws + p->part);
   const int RL = 256 / (C / 4);
   long per = (M + STAT_CHUNKS - 1) / STAT_CHUNKS;
+  if (per < 16L * RL) per = 16L * RL;   // >= 16 rows per thread: fewer, fuller chunks for the small deep layers (the finalize
+                                         // kernels read every chunk's partial sums)
   per = (per + RL - 1) / RL * RL;
-  if (per < RL) per = RL;
   c.rows_per_chunk = per;
   c.nchunk = cdiv(M, per);
   return c;
