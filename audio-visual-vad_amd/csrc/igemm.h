@@ -210,8 +210,11 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
            const int full_rounds, const int rem_tiles, const int kchunks) {
   typedef Stage<AOp, BM, NTH> SA;
   typedef Stage<BOp, BN, NTH> SB;
-  constexpr int WGN = NTH / 128;                  // waves along N (2 or 4); 2 along M
-  constexpr int TM = BM / 64, TN = BN / (32 * WGN);
+  // wave grid WGM x WGN: 2 x 2 (256 threads), 2 x 4 (512 threads, 128x128) or 4 x 2 (512 threads, 256x64: the tall tile
+  // of the 64-channel convolutions); every wave owns a (BM/WGM) x (BN/WGN) = TM x TN grid of 32x32 accumulators
+  constexpr int WGN = (BM == 256) ? 2 : NTH / 128;
+  constexpr int WGM = NTH / 64 / WGN;
+  constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
   constexpr int TILE = BK * SA::LD + BK * SB::LD;
   __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * TILE];
 
@@ -327,7 +330,7 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
       const int cur = DB ? ((kt - kt0) & 1) : 0;
       float* As = smem + cur * TILE;
       float* Bs = As + BK * SA::LD;
-      const float* ap = As + lh * SA::LD + wm * (BM / 2) + li;
+      const float* ap = As + lh * SA::LD + wm * (BM / WGM) + li;
       const float* bp = Bs + lh * SB::LD + wn * (BN / WGN) + li;
       float a[2][TM], b[2][TN];
 #pragma unroll
@@ -394,7 +397,7 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WGN) + j * 32 + li;
         const float bv = (E.bias && n < N && kt0 == 0) ? E.bias[n] : 0.f;
-        const int mb = m0 + wm * (BM / 2) + i * 32;
+        const int mb = m0 + wm * (BM / WGM) + i * 32;
         if constexpr (std::is_same<Epi, EpiStore>::value) {
           if (fast) {
             const unsigned ld32 = (unsigned)E.ldc;
@@ -459,10 +462,12 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   const long iters = ntiles * ktiles;
   const char* var = getenv("AVVAD_IGEMM_VARIANT");  // tuning aid: "db"/"sb" = 4-wave double/single LDS buffer, "w8" = 8 waves
   constexpr bool BIG = (BM == 128 && BN == 128);
-  const int variant = var ? (var[0] == 'd' ? 0 : (var[0] == 's' ? 1 : 2)) : (BIG ? 2 : 1);
+  constexpr bool TALL = (BM == 256);             // 256x64, 8 waves as 4x2, single LDS buffer (41.6 KB), 2 workgroups / CU
+  const int variant = TALL ? 3 : (var ? (var[0] == 'd' ? 0 : (var[0] == 's' ? 1 : 2)) : (BIG ? 2 : 1));
   // resident workgroups per CU (LDS footprint / VGPR budget of the instantiation)
   int per_cu;
-  if (variant == 0) per_cu = BIG ? 2 : (BM * BN >= 128 * 64 ? 3 : 4);
+  if (variant == 3) per_cu = 2;
+  else if (variant == 0) per_cu = BIG ? 2 : (BM * BN >= 128 * 64 ? 3 : 4);
   else if (variant == 1 || !BIG) per_cu = BIG ? 3 : (BM * BN >= 128 * 64 ? 4 : 6);
   else per_cu = 2;
   long G = (long)NUM_CU * per_cu;
@@ -510,13 +515,17 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
     }
   }
   const int fr = (int)full_rounds, rt = (int)rem;
-  if (variant == 0)
-    hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
-  else if (variant == 1 || !BIG)
-    hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
-  else
-    hipLaunchKernelGGL((kernel<BM, BN, true, (BIG ? 512 : 256), AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K,
-                       ktiles, fr, rt, kchunks);
+  if constexpr (TALL) {
+    hipLaunchKernelGGL((kernel<BM, BN, false, 512, AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
+  } else {
+    if (variant == 0)
+      hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
+    else if (variant == 1 || !BIG)
+      hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
+    else
+      hipLaunchKernelGGL((kernel<BM, BN, true, (BIG ? 512 : 256), AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K,
+                         ktiles, fr, rt, kchunks);
+  }
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

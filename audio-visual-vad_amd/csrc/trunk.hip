@@ -247,7 +247,7 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
   const int T = g.KS * g.KS;
   convop::ColTapRows b{wf, g.Co, g.Co, K, g.C, T, convop::div_magic(T)};
   convop::Im2colFwd a{x, g, M, convop::tap_div(T, g.KS)};
-  if (g.Co <= 64) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
+  if (g.Co <= 64) return getenv("AVVAD_NO_TALL") ? igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s) : igemm::launch<256, 64>(a, b, e, M, g.Co, K, 1, s);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s);
 }
 // dx (+)= dgrad
@@ -289,7 +289,7 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
   const int T = g.KS * g.KS;
   convop::ColTapRows b{wd, g.C, g.C, K, g.Co, T, convop::div_magic(T)};
   convop::Im2colDgrad a{dy, g, M, convop::tap_div(T, g.KS)};
-  if (g.C <= 64) return igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s);
+  if (g.C <= 64) return getenv("AVVAD_NO_TALL") ? igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s) : igemm::launch<256, 64>(a, b, e, M, g.C, K, 1, s);
   return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s);
 }
 // pk[(kh,kw,c)][co] = wgrad (pk zeroed here; split-K partials are added atomically)
