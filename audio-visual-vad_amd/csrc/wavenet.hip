@@ -568,6 +568,116 @@ __global__ void __launch_bounds__(256)
   for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
 }
 
+// ------------------------------------------------------------------ (A) + weight gradients in ONE pass
+// wn_block_bwd_dz_mfma and wn_block_wgrad_mfma fused: the weight-gradient kernel re-read dS, Z and DZ (3 of its 5
+// operand tiles, 150 MB per layer) that the dz kernel had just held in registers.  Here a wave computes dz for its
+// 32-sample tile, stores it, and feeds the same registers -- plus the two shifted s_in tiles -- through the per-wave
+// 32x33 LDS transpose into the three resident weight-gradient accumulators.
+__global__ void __launch_bounds__(256)
+    wn_block_bwd_dz_wgrad_mfma(const float* __restrict__ dS, const float* __restrict__ Z, const float* __restrict__ w_dense,
+                               const float* __restrict__ s_in, float* __restrict__ DZ, float* __restrict__ slab, int B,
+                               int Lin, int dil) {
+  __shared__ float tile[4][32 * 33];
+  __shared__ float red[3 * 1024 + 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  float* T = tile[wave];
+  // W_dense through this wave's transpose tile: A[i = d = li][k = r = 2s+lh] = W_dense[r][d]
+  for (int i = lane; i < 1024; i += 64) T[(i >> 5) * 33 + (i & 31)] = w_dense[i];
+  __builtin_amdgcn_wave_barrier();
+  float wt[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) wt[s] = T[(2 * s + lh) * 33 + li];
+  __builtin_amdgcn_wave_barrier();
+  for (int i = threadIdx.x; i < 3 * 1024 + 64; i += 256) red[i] = 0.f;
+
+  f32x16 acc0, acc1, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+  float bs_dz = 0.f, bs_ds = 0.f;
+
+  auto gl = [&](const float* base, long rstride, float (&v)[16]) {   // v[q] = X[channel 2q+lh][time li]
+#pragma unroll
+    for (int q = 0; q < 16; ++q) v[q] = base[(long)(2 * q + lh) * rstride];
+  };
+  // values given as X[channel chan(q)][time li] -> fragment f[q] = X[channel li][time 2q+lh]
+  auto xpose = [&](const float (&v)[16], bool ok, bool relu, bool dlayout, float (&f)[16]) {
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float x = ok ? v[q] : 0.f;
+      const int ch = dlayout ? mfma32_row(q, lh) : 2 * q + lh;
+      T[ch * 33 + li] = relu ? fmaxf(x, 0.f) : x;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) f[q] = T[li * 33 + 2 * q + lh];
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  for (long tl = wave0; tl < ntiles; tl += nwaves) {
+    const int b = (int)(tl / tiles_per_seq);
+    const int t = (int)(tl - (long)b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lo;
+    const long oo = (long)b * 32 * Lo + (ok ? t : 0);
+    const long oi = (long)b * 32 * Lin + (ok ? t : 0);
+    float g[16], z[16], s0[16], s1[16];   // all four operand tiles in flight at once (unconditional, clamped; masked later)
+    gl(dS + oo, Lo, g);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = Z[oo + (long)mfma32_row(r, lh) * Lo];
+    gl(s_in + oi, Lin, s0);
+    gl(s_in + oi + dil, Lin, s1);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[q] = ok ? g[q] : 0.f;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = mfma32(wt[q], g[q], acc);
+    float dz[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      dz[r] = z[r] > 0.f ? acc[r] : 0.f;
+      if (ok) DZ[oo + (long)mfma32_row(r, lh) * Lo] = dz[r];
+    }
+    float fa[16], fb[16];
+    xpose(dz, ok, false, true, fa);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bs_dz += fa[q];
+    xpose(s0, ok, true, false, fb);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc0 = mfma32(fa[q], fb[q], acc0);
+    xpose(s1, ok, true, false, fb);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1 = mfma32(fa[q], fb[q], acc1);
+    xpose(g, ok, false, false, fa);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) bs_ds += fa[q];
+    xpose(z, ok, true, true, fb);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2 = mfma32(fa[q], fb[q], acc2);
+  }
+
+  __syncthreads();  // red[] zeroed
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mfma32_row(r, lh);
+    atomicAdd(&red[row * 32 + li], acc0[r]);
+    atomicAdd(&red[1024 + row * 32 + li], acc1[r]);
+    atomicAdd(&red[2048 + row * 32 + li], acc2[r]);
+  }
+  atomicAdd(&red[3072 + li], bs_dz);
+  atomicAdd(&red[3104 + li], bs_ds);
+  __syncthreads();
+  float* out = slab + (long)blockIdx.x * WG_SLAB;
+  for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
+}
+
 // dW_dil[d][c][k] += sum_blocks slab[k*1024 + d*32 + c]; dW_dense[r][d] += slab[2048 + r*32 + d]; biases likewise
 __global__ void __launch_bounds__(256)
     wn_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restrict__ dW_dil, float* __restrict__ db_dil,
@@ -753,16 +863,28 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     if (fast) {
       // dz = (z>0) * W_dense^T dS ; then all four parameter gradients in one pass ; then d s_i
       long blocks = ((long)B * cdiv(Lo, 32) + 3) / 4;
-      if (blocks > 768) blocks = 768;
-      hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], DZ, B, Lo);
-      if (g->dil_w_h[i] && g->dense_w_h[i]) {
+      if (g->dil_w_h[i] && g->dense_w_h[i] && !getenv("AVVAD_WN_NO_FUSED_WGRAD")) {
+        // dz AND the four parameter gradients in one pass over dS, Z and the two shifted s_i tiles
         long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave
         if (wb > WG_MAXBLK) wb = WG_MAXBLK;
         if (wb < 1) wb = 1;
-        hipLaunchKernelGGL(wn_block_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, DZ, si, ws + p.slab, B, Li, dil);
+        hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], si, DZ,
+                           ws + p.slab, B, Li, dil);
         hipLaunchKernelGGL(wn_wgrad_reduce, dim3(cdiv(WG_SLAB, 256), 32), dim3(256), 0, s, ws + p.slab, (int)wb, g->dil_w_h[i],
                            d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
                            d->use_bias ? g->dense_b_h[i] : (float*)nullptr);
+      } else {
+        if (blocks > 768) blocks = 768;
+        hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], DZ, B, Lo);
+        if (g->dil_w_h[i] && g->dense_w_h[i]) {
+          long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave
+          if (wb > WG_MAXBLK) wb = WG_MAXBLK;
+          if (wb < 1) wb = 1;
+          hipLaunchKernelGGL(wn_block_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, DZ, si, ws + p.slab, B, Li, dil);
+          hipLaunchKernelGGL(wn_wgrad_reduce, dim3(cdiv(WG_SLAB, 256), 32), dim3(256), 0, s, ws + p.slab, (int)wb, g->dil_w_h[i],
+                             d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
+                             d->use_bias ? g->dense_b_h[i] : (float*)nullptr);
+        }
       }
       blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
       if (blocks > 512) blocks = 512;
