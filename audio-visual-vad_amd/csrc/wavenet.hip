@@ -568,17 +568,21 @@ __global__ void __launch_bounds__(256)
   for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
 }
 
-// ------------------------------------------------------------------ (A) + weight gradients in ONE pass
-// wn_block_bwd_dz_mfma and wn_block_wgrad_mfma fused: the weight-gradient kernel re-read dS, Z and DZ (3 of its 5
-// operand tiles, 150 MB per layer) that the dz kernel had just held in registers.  Here a wave computes dz for its
-// 32-sample tile, stores it, and feeds the same registers -- plus the two shifted s_in tiles -- through the per-wave
-// 32x33 LDS transpose into the three resident weight-gradient accumulators.
+// ------------------------------------------------------------------ (A) + weight gradients in ONE pass, z recomputed
+// wn_block_bwd_dz_mfma and wn_block_wgrad_mfma fused, and the forward no longer stores z: per 32-sample tile a wave loads
+// dS (16 values) and the two dilation taps of s_in (lane half h = tap h, 32 channels: the forward's own operand), rebuilds
+// z = b + W_dil (*) relu(s_in) with the forward's exact MFMA sequence (bit-identical, so the ReLU masks agree), forms
+// dz = (z>0) * W_dense^T dS, stores it, and pushes dz / relu(s taps) / dS / relu(z) through per-wave 32x33 LDS
+// transposes into the three resident weight-gradient accumulators.  Per layer this replaces 350 MB of HBM traffic
+// (z written by the forward, dS + Z read twice, DZ re-read) by 150 MB; the encoder shares HBM with the trunk's
+// convolutions running on the other stream, so the bytes matter beyond this kernel's own time.
 __global__ void __launch_bounds__(256)
-    wn_block_bwd_dz_wgrad_mfma(const float* __restrict__ dS, const float* __restrict__ Z, const float* __restrict__ w_dense,
-                               const float* __restrict__ s_in, float* __restrict__ DZ, float* __restrict__ slab, int B,
-                               int Lin, int dil) {
-  __shared__ float tile[4][32 * 33];
+    wn_block_bwd_dz_wgrad_mfma(const float* __restrict__ dS, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
+                               const float* __restrict__ w_dense, const float* __restrict__ s_in, float* __restrict__ DZ,
+                               float* __restrict__ slab, int B, int Lin, int dil) {
+  __shared__ float tile[4][2][32 * 33];
   __shared__ float red[3 * 1024 + 64];
+  __shared__ float wl[32 * 65 + 32];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int Lo = Lin - dil;
@@ -586,84 +590,117 @@ __global__ void __launch_bounds__(256)
   const long ntiles = (long)B * tiles_per_seq;
   const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
-  float* T = tile[wave];
+  float* T = tile[wave][0];
+  float* Th = tile[wave][lh];           // this lane half's tile for the two-tap transpose
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  if (threadIdx.x < 32) wl[2080 + threadIdx.x] = b_dil ? b_dil[threadIdx.x] : 0.f;
   // W_dense through this wave's transpose tile: A[i = d = li][k = r = 2s+lh] = W_dense[r][d]
-  for (int i = lane; i < 1024; i += 64) T[(i >> 5) * 33 + (i & 31)] = w_dense[i];
-  __builtin_amdgcn_wave_barrier();
+  {
+    float wv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) wv[u] = w_dense[lane + 64 * u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { const int i = lane + 64 * u; T[(i >> 5) * 33 + (i & 31)] = wv[u]; }
+  }
+  for (int i = threadIdx.x; i < 3 * 1024 + 64; i += 256) red[i] = 0.f;
+  __syncthreads();
   float wt[16];
 #pragma unroll
   for (int s = 0; s < 16; ++s) wt[s] = T[(2 * s + lh) * 33 + li];
+  float wd[32];   // W_dil[d = li][c = s][tap = lh]  (the forward's fragment)
+#pragma unroll
+  for (int s = 0; s < 32; ++s) wd[s] = wl[li * 65 + s * 2 + lh];
+  const float* bzl = wl + 2080;
   __builtin_amdgcn_wave_barrier();
-  for (int i = threadIdx.x; i < 3 * 1024 + 64; i += 256) red[i] = 0.f;
 
   f32x16 acc0, acc1, acc2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
   float bs_dz = 0.f, bs_ds = 0.f;
 
-  auto gl = [&](const float* base, long rstride, float (&v)[16]) {   // v[q] = X[channel 2q+lh][time li]
+  // software pipeline across tiles (as in wn_block_fwd_mfma): the NEXT tile's 48 loads are issued before this tile's 96
+  // MFMAs and LDS transposes -- with one wave per SIMD nothing else hides their latency
+  float gn[16], xn[32];
+  auto issue = [&](long tile) {
+    const long tc = tile < ntiles ? tile : ntiles - 1;
+    const int b = (int)(tc / tiles_per_seq);
+    const int t = (int)(tc - (long)b * tiles_per_seq) * 32 + li;
+    const int tcl = t < Lo ? t : 0;
+    const long oo = (long)b * 32 * Lo + tcl;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) v[q] = base[(long)(2 * q + lh) * rstride];
+    for (int q = 0; q < 16; ++q) gn[q] = dS[oo + (long)(2 * q + lh) * Lo];
+    const float* xp = s_in + (long)b * 32 * Lin + tcl + lh * dil;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) xn[c] = xp[(long)c * Lin];
   };
-  // values given as X[channel chan(q)][time li] -> fragment f[q] = X[channel li][time 2q+lh]
-  auto xpose = [&](const float (&v)[16], bool ok, bool relu, bool dlayout, float (&f)[16]) {
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const float x = ok ? v[q] : 0.f;
-      const int ch = dlayout ? mfma32_row(q, lh) : 2 * q + lh;
-      T[ch * 33 + li] = relu ? fmaxf(x, 0.f) : x;
-    }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int q = 0; q < 16; ++q) f[q] = T[li * 33 + 2 * q + lh];
-    __builtin_amdgcn_wave_barrier();
-  };
-
+  if (wave0 < ntiles) issue(wave0);
   for (long tl = wave0; tl < ntiles; tl += nwaves) {
     const int b = (int)(tl / tiles_per_seq);
     const int t = (int)(tl - (long)b * tiles_per_seq) * 32 + li;
     const bool ok = t < Lo;
-    const long oo = (long)b * 32 * Lo + (ok ? t : 0);
-    const long oi = (long)b * 32 * Lin + (ok ? t : 0);
-    float g[16], z[16], s0[16], s1[16];   // all four operand tiles in flight at once (unconditional, clamped; masked later)
-    gl(dS + oo, Lo, g);
+    const int tcl = ok ? t : 0;
+    const long oo = (long)b * 32 * Lo + tcl;
+    float g[16], x[32];     // unconditional, clamped loads (masked here)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = Z[oo + (long)mfma32_row(r, lh) * Lo];
-    gl(s_in + oi, Lin, s0);
-    gl(s_in + oi + dil, Lin, s1);
+    for (int q = 0; q < 16; ++q) g[q] = ok ? gn[q] : 0.f;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) g[q] = ok ? g[q] : 0.f;
+    for (int c = 0; c < 32; ++c) x[c] = ok ? fmaxf(xn[c], 0.f) : 0.f;      // relu(s tap lh), zero outside the tile
+    issue(tl + nwaves);
+    // pin the 48 loads HERE: left alone hipcc sinks each one down to its consumer (load, wait, mfma, load, wait, ...),
+    // 32 serial memory round trips per tile -- the kernel ran 2.5x slower than the two it replaces
+    __builtin_amdgcn_sched_barrier(0);
+    // z exactly as wn_block_fwd_mfma builds it
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = bzl[mfma32_row(r, lh)];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) z = mfma32(wd[s], x[s], z);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc = mfma32(wt[q], g[q], acc);
-    float dz[16];
+    float f0[16], f1[16];
+    // ---- dz (D layout: rows mfma32_row(r, lh), column = time li) -> store, transpose
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      dz[r] = z[r] > 0.f ? acc[r] : 0.f;
-      if (ok) DZ[oo + (long)mfma32_row(r, lh) * Lo] = dz[r];
+      const float dz = (ok && z[r] > 0.f) ? acc[r] : 0.f;
+      if (ok) DZ[oo + (long)mfma32_row(r, lh) * Lo] = dz;
+      T[mfma32_row(r, lh) * 33 + li] = dz;
     }
-    float fa[16], fb[16];
-    xpose(dz, ok, false, true, fa);
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bs_dz += fa[q];
-    xpose(s0, ok, true, false, fb);
+    for (int q = 0; q < 16; ++q) { f0[q] = T[li * 33 + 2 * q + lh]; bs_dz += f0[q]; }   // f0 = dz[d = li][t = 2q+lh]
+    __builtin_amdgcn_wave_barrier();
+    // ---- both taps of relu(s): lane half h writes its 32 channels into tile h
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc0 = mfma32(fa[q], fb[q], acc0);
-    xpose(s1, ok, true, false, fb);
+    for (int c = 0; c < 32; ++c) Th[c * 33 + li] = x[c];
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc1 = mfma32(fa[q], fb[q], acc1);
-    xpose(g, ok, false, false, fa);
+    for (int q = 0; q < 16; ++q) f1[q] = tile[wave][0][li * 33 + 2 * q + lh];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) bs_ds += fa[q];
-    xpose(z, ok, true, true, fb);
+    for (int q = 0; q < 16; ++q) acc0 = mfma32(f0[q], f1[q], acc0);
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc2 = mfma32(fa[q], fb[q], acc2);
+    for (int q = 0; q < 16; ++q) f1[q] = tile[wave][1][li * 33 + 2 * q + lh];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1 = mfma32(f0[q], f1[q], acc1);
+    __builtin_amdgcn_wave_barrier();
+    // ---- dS (channel 2q+lh on register q) and relu(z) (D layout)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) T[(2 * q + lh) * 33 + li] = g[q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[wave][1][mfma32_row(r, lh) * 33 + li] = ok ? fmaxf(z[r], 0.f) : 0.f;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { f0[q] = T[li * 33 + 2 * q + lh]; bs_ds += f0[q]; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) f1[q] = tile[wave][1][li * 33 + 2 * q + lh];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2 = mfma32(f0[q], f1[q], acc2);
+    __builtin_amdgcn_wave_barrier();
   }
 
-  __syncthreads();  // red[] zeroed
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = mfma32_row(r, lh);
@@ -718,7 +755,10 @@ static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
     const size_t big = B * (size_t)(d->R > d->D ? d->R : d->D) * p->L[0];
     p->z = take(big); p->dz = take(big); p->ga = take(big); p->gb = take(big);
     p->dzt = take(B * d->Bn * p->L[p->n]);
-    for (int i = 0; i < p->n; ++i) p->zs[i] = (d->R == 32 && d->D == 32 && d->fw == 2) ? take(B * d->D * p->L[i + 1]) : 0;
+    {   // one scratch z buffer (only the unfused backward fallback rebuilds z into it)
+      const size_t zb = (d->R == 32 && d->D == 32 && d->fw == 2 && p->n > 0) ? take(B * d->D * p->L[1]) : 0;
+      for (int i = 0; i < p->n; ++i) p->zs[i] = zb;
+    }
     p->slab = take((size_t)WG_MAXBLK * WG_SLAB);
   } else {
     for (int i = 0; i < p->n; ++i) p->zs[i] = 0;
@@ -783,11 +823,8 @@ extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* 
       const long ntiles = (long)B * cdiv(p.L[i + 1], 32);
       long blocks = (ntiles + 3) / 4;
       if (blocks > 512) blocks = 512;    // 2 waves per SIMD resident; each wave walks >= 5 tiles at the bench shape
-      if (d->save_for_backward)   // keep z: one more write now, no recompute pass in backward
-        hipLaunchKernelGGL(wn_block_fwd_mfma<1>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
-                           prm->dense_w_h[i], be, ws + p.s[i + 1], ws + p.zs[i], B, p.L[i], dil);
-      else
-        hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
+      // z (pre-ReLU dilation output) is NOT kept: backward rebuilds it from s_i inside its fused kernel, bit-identically
+      hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
                            prm->dense_w_h[i], be, ws + p.s[i + 1], (float*)nullptr, B, p.L[i], dil);
     } else {
       float* z = ws + p.z;
@@ -868,12 +905,16 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
         long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave
         if (wb > WG_MAXBLK) wb = WG_MAXBLK;
         if (wb < 1) wb = 1;
-        hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], si, DZ,
-                           ws + p.slab, B, Li, dil);
+        hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd,
+                           prm->dense_w_h[i], si, DZ, ws + p.slab, B, Li, dil);
         hipLaunchKernelGGL(wn_wgrad_reduce, dim3(cdiv(WG_SLAB, 256), 32), dim3(256), 0, s, ws + p.slab, (int)wb, g->dil_w_h[i],
                            d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
                            d->use_bias ? g->dense_b_h[i] : (float*)nullptr);
       } else {
+        // (frozen weights / tuning switch) separate kernels: z is not kept by the forward -> rebuild it first
+        long fb = blocks > 512 ? 512 : blocks;
+        hipLaunchKernelGGL(wn_block_fwd_mfma<2>, dim3((int)fb), dim3(256), 0, s, si, prm->dil_w_h[i], bd, prm->dense_w_h[i],
+                           (const float*)nullptr, (float*)nullptr, Zi, B, Li, dil);
         if (blocks > 768) blocks = 768;
         hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], DZ, B, Lo);
         if (g->dil_w_h[i] && g->dense_w_h[i]) {
