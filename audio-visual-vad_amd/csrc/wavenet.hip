@@ -903,6 +903,9 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
       if (g->dil_w_h[i] && g->dense_w_h[i] && !getenv("AVVAD_WN_NO_FUSED_WGRAD")) {
         // dz AND the four parameter gradients in one pass over dS, Z and the two shifted s_i tiles
         long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave
+        // one workgroup per CU is resident (368 VGPRs): ONE round of 256, not two of 512 -- every workgroup pays a weight
+        // staging prologue and a 12.5 KB slab epilogue (step 22.57 -> 22.06 ms; 128..256 workgroups time the same)
+        if (wb > 256) wb = 256;
         if (wb > WG_MAXBLK) wb = WG_MAXBLK;
         if (wb < 1) wb = 1;
         hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd,
