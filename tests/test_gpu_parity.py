@@ -264,12 +264,22 @@ def test_video_net_golden_eval_and_train():
     assert int(sd["features.1.num_batches_tracked"]) == 1
 
 
-@pytest.mark.parametrize("training", [True, False])
-def test_trunk_backward_vs_oracle(training):
-    """gradients of a random projection of the features w.r.t. every trunk parameter."""
+@pytest.mark.parametrize("training,streamk", [(True, False), (False, False), (True, True), (False, True)])
+def test_trunk_backward_vs_oracle(training, streamk, monkeypatch):
+    """gradients of a random projection of the features w.r.t. every trunk parameter.
+
+    streamk=False runs the engine with whole-tile scheduling (AVVAD_NO_STREAMK=all): bit-reproducible, and held to
+    the strict bounds.  streamk=True is the production schedule: the pieces of a split tile are added with float
+    atomics in arrival order, i.e. a different (equally valid) fp32 summation order from run to run (~1e-6 in the
+    forward; train-mode BatchNorm over this 6-frame batch amplifies it to ~1e-5).  ONE ReLU decision that lands on the
+    other side of zero then moves every upstream gradient by ~3e-3 relative L2 (measured: sign pattern of the last
+    block's output differs in 1 of 27648 entries in ~60 % of train-mode runs, and about once in 20 eval-mode runs), so
+    that pass gets the flip-tolerant relative bound.  An indexing bug gives O(1) relative error under either."""
     from oracle import resnet18
     from avvad import nn as avnn
     from packages.models.Video_Net import DeepVAD_video
+    if not streamk:
+        monkeypatch.setenv("AVVAD_NO_STREAMK", "all")
     sd0 = _video_state()
     N = 6
     x = stategen.rand(21, N, 67, 67)
@@ -282,15 +292,11 @@ def test_trunk_backward_vs_oracle(training):
     m.load_state_dict(sd0)
     m = m.to(DEV).train(training)
     f = avnn.trunk_forward(m.features, x.to(DEV), training)
-    _report("trunk fwd (training=%s)" % training, f, ref, 1e-4, 1e-5)
+    _report("trunk fwd (training=%s, streamk=%s)" % (training, streamk), f, ref, 1e-4, 1e-5)
     (f * G.to(DEV)).sum().backward()
-    # train-mode BatchNorm over a 6-frame batch amplifies fp32 summation-order noise (the stream-K pieces of a
-    # tile are added in arrival order) to ~1e-5 in the forward; ONE ReLU decision that lands on the other side of
-    # zero then moves every upstream gradient by ~3e-3 relative L2 (measured: sign pattern of the last block's
-    # output differs in 1 of 27648 entries in ~60 % of runs; AVVAD_NO_STREAMK=all is bit-reproducible and matches
-    # to 1e-6).  Eval mode has no such amplification and keeps the strict bound.
+    rel = 2e-2 if streamk else (5e-3 if training else 2e-3)
     for k, p in m.features.named_parameters():
-        _report_grad("trunk d/d%s" % k, p.grad, sd["features." + k].grad, 2.0, 2e-2 if training else 2e-3)
+        _report_grad("trunk d/d%s" % k, p.grad, sd["features." + k].grad, 2.0, rel)
 
 
 def test_av_net_golden_concat():
