@@ -504,6 +504,141 @@ __global__ void __launch_bounds__(256)
 }
 
 
+// ------------------------------------------------------------------ tail backward + bottleneck weight/bias gradients in ONE pass
+// tail_bwd_mfma wrote dz_t (B x Bn x Lv: 268 MB at the bench shape) only so that a GEMM and a column sum could read it
+// back for dW_b = dz_t . s^T and db = sum_t dz_t: 800 MB of traffic for 8 K numbers.  Here each dz tile goes from the
+// accumulator through a per-wave 32x33 LDS transpose straight into NBT resident 32x32 weight-gradient accumulators
+// (dW_b[bn][c], one per 32-row bn tile), with the s tile transposed once per time tile; dz_t is never written.
+// Partial sums leave through per-workgroup slabs + a fixed-order reduce, like the residual blocks' gradients.
+template <int NBT>   // Bn / 32
+__global__ void __launch_bounds__(256)
+    tail_bwd_wgrad_mfma(const float* __restrict__ s, const float* __restrict__ wb, const float* __restrict__ bb,
+                        const float* __restrict__ dout, float* __restrict__ dS, float* __restrict__ slab, int B, int Lv, int P) {
+  constexpr int Bn = NBT * 32;
+  constexpr int SLAB = Bn * 32 + Bn;
+  extern __shared__ float dyn[];
+  float* wl = dyn;                       // Bn x 33 padded weights
+  float* red = dyn + Bn * 33;            // SLAB partial sums of this workgroup
+  float* tiles = red + SLAB;             // 4 waves x 2 transpose tiles of 32 x 33
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_per_seq = (Lv + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  float* T0 = tiles + wave * 2 * 1056;   // s tile
+  float* T1 = T0 + 1056;                 // dz tile
+  for (int i = threadIdx.x; i < Bn * 32; i += 256) wl[(i >> 5) * 33 + (i & 31)] = wb[i];
+  for (int i = threadIdx.x; i < SLAB; i += 256) red[i] = 0.f;
+  __syncthreads();
+  f32x16 accW[NBT];
+  float bsum[NBT];
+#pragma unroll
+  for (int n = 0; n < NBT; ++n) {
+    bsum[n] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[n][r] = 0.f;
+  }
+  for (long tile = wave0; tile < ntiles; tile += nwaves) {
+    const int b = (int)(tile / tiles_per_seq);
+    const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lv;
+    const float* sp = s + (long)b * 32 * Lv + (ok ? t : 0);
+    float x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = sp[(long)(2 * k + lh) * Lv];
+    __builtin_amdgcn_sched_barrier(0);     // keep the 16 loads together (see wn_block_bwd_dz_wgrad_mfma)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = ok ? x[k] : 0.f;
+    int pb[3];
+    float pc[3];
+    {
+      const int c0 = ok ? (int)(((long)t * P) / Lv) : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int p = c0 - 1 + j;
+        int a = 0, e = 0;
+        const bool in = ok && p >= 0 && p < P;
+        if (in) pool_bin(p, Lv, P, a, e);
+        const bool hit = in && t >= a && t < e;
+        pb[j] = hit ? p : 0;
+        pc[j] = hit ? 1.f / (float)(e - a) : 0.f;
+      }
+    }
+    // s tile -> fragment fs[q] = s[c = li][t = 2q + lh]  (B operand of the weight-gradient products)
+    float fs[16];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T0[(2 * k + lh) * 33 + li] = x[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) fs[q] = T0[li * 33 + 2 * q + lh];
+    f32x16 accS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accS[r] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NBT; ++n) {
+      const int nb = n * 32;
+      float wz[16], wt[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        wz[k] = wl[(nb + li) * 33 + 2 * k + lh];                  // A[i = bn][k = c] for z
+        wt[k] = wl[(nb + mfma32_row(k, lh)) * 33 + li];            // A[i = c][k = bn] for dS
+      }
+      f32x16 accZ;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accZ[r] = bb ? bb[nb + mfma32_row(r, lh)] : 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) accZ = mfma32(wz[k], x[k], accZ);
+      float dz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const long o = ((long)b * Bn + nb + mfma32_row(r, lh)) * P;
+        float g = 0.f;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) g = fmaf(dout[o + pb[j]], pc[j], g);   // pb clamped to a valid bin, pc = 0 when not a member
+        dz[r] = accZ[r] > 0.f ? g : 0.f;                                   // (0 outside the sequence: pc = 0)
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accS = mfma32(wt[r], dz[r], accS);
+      // dz tile (rows bn, column time) -> fragment fz[q] = dz[bn = li][t = 2q + lh]
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T1[mfma32_row(r, lh) * 33 + li] = dz[r];
+      __builtin_amdgcn_wave_barrier();
+      float fz[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { fz[q] = T1[li * 33 + 2 * q + lh]; bsum[n] += fz[q]; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accW[n] = mfma32(fz[q], fs[q], accW[n]);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok) dS[((long)b * 32 + mfma32_row(r, lh)) * Lv + t] = accS[r];
+  }
+#pragma unroll
+  for (int n = 0; n < NBT; ++n) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) atomicAdd(&red[(n * 32 + mfma32_row(r, lh)) * 32 + li], accW[n][r]);
+    atomicAdd(&red[Bn * 32 + n * 32 + li], bsum[n]);
+  }
+  __syncthreads();
+  float* out = slab + (long)blockIdx.x * SLAB;
+  for (int i = threadIdx.x; i < SLAB; i += 256) out[i] = red[i];
+}
+
+// dW_b[bn][c] += sum_blocks slab[bn*32 + c]; db[bn] += slab[Bn*32 + bn]
+__global__ void __launch_bounds__(256)
+    tail_wgrad_reduce(const float* __restrict__ slab, int nslab, int Bn, float* __restrict__ dW, float* __restrict__ db) {
+  const int n = Bn * 32 + Bn;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float sum = 0.f;
+  for (int b = blockIdx.y; b < nslab; b += gridDim.y) sum += slab[(long)b * n + i];
+  if (i < Bn * 32) { if (dW) atomicAdd(dW + i, sum); }
+  else if (db) atomicAdd(db + i - Bn * 32, sum);
+}
+
 constexpr int WG_SLAB = 3 * 1024 + 64;   // per-workgroup partial sums of wn_block_wgrad_mfma
 constexpr int WG_MAXBLK = 512;
 
@@ -792,7 +927,10 @@ static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
       const size_t zb = (d->R == 32 && d->D == 32 && d->fw == 2 && p->n > 0) ? take(B * d->D * p->L[1]) : 0;
       for (int i = 0; i < p->n; ++i) p->zs[i] = zb;
     }
-    p->slab = take((size_t)WG_MAXBLK * WG_SLAB);
+    {   // weight-gradient slabs: residual blocks (WG_MAXBLK x WG_SLAB) or the tail (256 workgroups x (Bn*32 + Bn))
+      const size_t a = (size_t)WG_MAXBLK * WG_SLAB, b2 = (size_t)256 * ((size_t)d->Bn * 33);
+      p->slab = take(a > b2 ? a : b2);
+    }
   } else {
     for (int i = 0; i < p->n; ++i) p->zs[i] = 0;
     const size_t a = take(B * d->R * p->L[0]), b2 = take(B * d->R * p->L[0]);
@@ -905,7 +1043,23 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
   // ---- tail: dz_t = relu'(z) * pooled-grad ; d s_N = Wb^T dz_t
   float* DZT = ws + p.dzt;
   const bool tail_mfma = (R == 32 && Bn % 32 == 0 && Bn <= 1024);
-  if (tail_mfma) {
+  const bool tail_fused = tail_mfma && Bn == 256 && g->bott_w && !getenv("AVVAD_WN_NO_FUSED_TAIL");
+  if (tail_fused) {
+    // d s_N and the bottleneck's weight + bias gradients in one pass; dz_t is never materialised
+    long blocks = ((long)B * cdiv(Lv, 32) + 3) / 4;
+    if (blocks > 256) blocks = 256;        // 1 workgroup / CU is resident: one round
+    const size_t lds = ((size_t)Bn * 33 + (size_t)Bn * 33 + 8 * 1056) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_wgrad_mfma<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds) != hipSuccess) return AVVAD_ELAUNCH;
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(tail_bwd_wgrad_mfma<8>, dim3((int)blocks), dim3(256), lds, s, ws + p.s[p.n], prm->bott_w,
+                       d->use_bias ? prm->bott_b : (const float*)nullptr, dout, GA, ws + p.slab, B, Lv, d->P);
+    hipLaunchKernelGGL(tail_wgrad_reduce, dim3(cdiv(Bn * 33, 256), 16), dim3(256), 0, s, ws + p.slab, (int)blocks, Bn, g->bott_w,
+                       d->use_bias ? g->bott_b : (float*)nullptr);
+  } else if (tail_mfma) {
     long blocks = ((long)B * cdiv(Lv, 32) + 3) / 4;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(tail_bwd_mfma, dim3((int)blocks), dim3(256), (size_t)Bn * 33 * sizeof(float), s, ws + p.s[p.n], prm->bott_w,
@@ -914,8 +1068,10 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     hipLaunchKernelGGL(tail_bwd_dz_generic, dim3(grid1((long)B * Bn * Lv)), dim3(256), 0, s, ws + p.s[p.n], prm->bott_w,
                        d->use_bias ? prm->bott_b : (const float*)nullptr, dout, DZT, B, R, Bn, Lv, d->P);
   }
-  if (g->bott_w && (rc = wgrad_conv1d(DZT, ws + p.s[p.n], g->bott_w, B, Bn, R, Lv, Lv, 1, 1, 0, s))) return rc;
-  if (d->use_bias) bias_grad(DZT, g->bott_b, B, Bn, Lv, s);
+  if (!tail_fused) {
+    if (g->bott_w && (rc = wgrad_conv1d(DZT, ws + p.s[p.n], g->bott_w, B, Bn, R, Lv, Lv, 1, 1, 0, s))) return rc;
+    if (d->use_bias) bias_grad(DZT, g->bott_b, B, Bn, Lv, s);
+  }
   if (!tail_mfma)
     hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Lv)), dim3(256), 0, s, DZT, prm->bott_w,
                        (const float*)nullptr, (const float*)nullptr, GA, B, R, Bn, Lv, Lv, 1, 1, 0, 0);
