@@ -56,7 +56,9 @@ __global__ void lstm_gates_fwd(float* __restrict__ G, float* __restrict__ Cs, fl
 // in LDS and the slice-0 waves finish the step.
 // (Tried: ONE persistent launch per layer with the W_hh fragments resident in registers and a grid barrier per step --
 //  correct, but 0.4 ms/step SLOWER end to end: the per-step release/acquire fences that carry h_t across XCDs write back
-//  and invalidate the whole L2, which costs more than re-streaming W_hh from the Infinity Cache.)
+//  and invalidate the whole L2, which costs more than re-streaming W_hh from the Infinity Cache.  Also tried: the same
+//  skinny treatment for the backward product dh = dG W_hh (64 columns x a K-split per workgroup, slabs summed by the gate
+//  kernel): equal to the stream-K GEMM within 0.1 ms -- both stream all of W_hh every step.)
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(1024)
     lstm_step_fwd_mfma(float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ y, const float* __restrict__ w_hh,
