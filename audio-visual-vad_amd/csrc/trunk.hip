@@ -146,6 +146,69 @@ __global__ void unpack_stem_wgrad(const float* __restrict__ pk, float* __restric
   dw[i] += pk[k * 64 + co];
 }
 
+// ------------------------------------------------------------------ stem convolution 7x7 / 2, 1 -> 64 channels (frames that fit LDS)
+// K = 49 is two K tiles of the engine: prologue + epilogue outweighed the loop and it ran at a quarter of the output-write
+// rate.  Here one workgroup owns one frame: the zero-padded frame is staged in LDS once (22 KB at 67x67), the 49x64
+// weights sit in registers as MFMA B fragments, and a wave walks 32-pixel tiles: the A fragment of k-step ks is ONE
+// ds_read_b32 (pixel base + tap offset: the im2col gather happens inside LDS), 25 k-steps x 2 column tiles = 50 MFMAs,
+// then 32 coalesced 128-byte row stores.
+__global__ void __launch_bounds__(256)
+    stem_fwd_mfma(const float* __restrict__ x, const float* __restrict__ wf, float* __restrict__ y, int H, int W, int Ho, int Wo,
+                  int LDW) {
+  extern __shared__ float img[];                     // (H + 6) x LDW, zero border of 3
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int PH = H + 6;
+  for (int i = threadIdx.x; i < PH * LDW; i += 256) img[i] = 0.f;
+  __syncthreads();
+  const float* xn = x + (long)n * H * W;
+  for (int i = threadIdx.x; i < H * W; i += 256) {
+    const int r = i / W, c = i - r * W;
+    img[(r + 3) * LDW + c + 3] = xn[i];
+  }
+  float b0[25], b1[25];
+  int toff[25];
+#pragma unroll
+  for (int ks = 0; ks < 25; ++ks) {
+    const int tap = 2 * ks + lh;
+    const bool live = tap < 49;
+    const int tc = live ? tap : 0;
+    b0[ks] = live ? wf[tc * 64 + li] : 0.f;
+    b1[ks] = live ? wf[tc * 64 + 32 + li] : 0.f;
+    toff[ks] = (tc / 7) * LDW + (tc % 7);
+  }
+  __syncthreads();
+  const int npix = Ho * Wo;
+  const int ntile = (npix + 31) >> 5;
+  float* yn = y + (long)n * npix * 64;
+  for (int tile = wave; tile < ntile; tile += 4) {
+    const int pix = tile * 32 + li;
+    const int pc = pix < npix ? pix : 0;              // clamped: rows beyond the frame are computed and dropped
+    const int ho = pc / Wo, wo = pc - ho * Wo;
+    const int base = 2 * ho * LDW + 2 * wo;           // padded coordinates: input row 2*ho - 3 + 3
+    float a[25];
+#pragma unroll
+    for (int ks = 0; ks < 25; ++ks) a[ks] = img[base + toff[ks]];
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 25; ++ks) {
+      acc0 = mfma32(a[ks], b0[ks], acc0);
+      acc1 = mfma32(a[ks], b1[ks], acc1);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = tile * 32 + mfma32_row(r, lh);
+      if (p < npix) {
+        yn[(long)p * 64 + li] = acc0[r];
+        yn[(long)p * 64 + 32 + li] = acc1[r];
+      }
+    }
+  }
+}
+
 // stem: p0 = maxpool3x3/2 pad1 ( relu(bn(c0)) )
 __global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
                                   float* __restrict__ p0, int N, int Hc, int Wc, int Hp, int Wp) {
@@ -238,6 +301,13 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
   const int M = g.N * g.Ho * g.Wo, K = g.KS * g.KS * g.C;
   igemm::EpiStore e{y, g.Co, nullptr, 0};
   if (g.C == 1) {
+    const int LDW = (g.W + 6) | 1;
+    const size_t lds = (size_t)(g.H + 6) * LDW * sizeof(float);
+    if (g.KS == 7 && g.stride == 2 && g.pad == 3 && g.Co == 64 && lds <= 48 * 1024 && !getenv("AVVAD_NO_STEM_KERNEL")) {
+      hipLaunchKernelGGL(stem_fwd_mfma, dim3(g.N), dim3(256), lds, s, x, wf, y, g.H, g.W, g.Ho, g.Wo, LDW);
+      AVVAD_LAUNCH_CHECK();
+      return AVVAD_OK;
+    }
     igemm::ColPlain<4> b{wf, g.Co, g.Co, K, 0};
     convop::StemFwd a{x, g, M, K};
     return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);

@@ -196,9 +196,12 @@ def test_adam_matches_torch():
 @pytest.mark.parametrize("N,H,W,C,Co,KS,stride,pad", [(3, 17, 17, 64, 64, 3, 1, 1), (2, 17, 17, 64, 128, 3, 2, 1),
                                                       (5, 9, 9, 128, 128, 3, 1, 1), (2, 17, 17, 64, 128, 1, 2, 0),
                                                       (3, 5, 5, 256, 512, 3, 2, 1), (4, 3, 3, 512, 512, 3, 1, 1),
-                                                      (2, 11, 7, 32, 36, 3, 1, 1), (2, 67, 67, 1, 64, 7, 2, 3)])
+                                                      (2, 11, 7, 32, 36, 3, 1, 1), (2, 67, 67, 1, 64, 7, 2, 3),
+                                                      (3, 40, 53, 1, 64, 7, 2, 3), (1, 120, 120, 1, 64, 7, 2, 3)])
 def test_conv2d_fwd_dgrad_wgrad(N, H, W, C, Co, KS, stride, pad):
-    """implicit-GEMM convolution (odd spatial sizes, stride 2, 1x1, the 7x7 stem) vs F.conv2d + autograd."""
+    """implicit-GEMM convolution (odd spatial sizes, stride 2, 1x1) and the 7x7 stem (LDS-resident frame kernel at
+    67x67 and at a ragged 40x53; the engine fallback at 120x120, whose padded frame exceeds the LDS budget) vs
+    F.conv2d + autograd."""
     import ctypes as Ct
     import torch.nn.functional as F
     from avvad import _lib as L
