@@ -32,9 +32,9 @@ W0 = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in ran
 RF = 2048
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
 # rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --no-extras`, dominant kernel, per
-# launch: FETCH_SIZE 99,897 KB x 2 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE 56,047 KB
+# launch: FETCH_SIZE 99,916 KB x 2 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE 56,047 KB
 # (tools/pmc_summary.py -> profiles/r01_pmc_{fetch,write}_size_per_kernel.csv)
-TRAFFIC_PER_LAUNCH_BYTES = int((2 * 99897 + 56047) * 1024)
+TRAFFIC_PER_LAUNCH_BYTES = int((2 * 99916 + 56047) * 1024)
 
 
 def make_inputs(torch, n_seq, seed, device):
