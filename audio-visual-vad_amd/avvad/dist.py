@@ -82,6 +82,8 @@ class BucketReducer:
         self.launched = [False] * len(self.buckets)
         self.handles = []
         self._hooks = []
+        self._names = {}
+        self._seen = set()
         if self.world > 1:
             for p in params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -92,11 +94,20 @@ class BucketReducer:
                 pass
 
     def _on_grad(self, p):
-        if id(p) not in self.param_bucket:
+        """A parameter's gradient for this step is complete (all kernels that write it are enqueued).  Called by
+        autograd's post-accumulate hook and/or by the HIP backward's in-place sinks: a parameter written in place can be
+        announced by BOTH (observed on torch 2.10: the hook also fires for the ``None`` the Function returns), so
+        repeats within a step are dropped -- counting them launched a bucket's all-reduce before its last gradients
+        existed (caught by tests/test_gpu_parity.py::test_two_rank_gpu_data_parallel_step).  Assumes what holds for these
+        models: every parameter is written by exactly one backward Function per step."""
+        if id(p) not in self.param_bucket or id(p) in self._seen:
             return
+        self._seen.add(id(p))
         b = self.param_bucket[id(p)]
         self.pending[b] += 1
-        if self.pending[b] == self.buckets[b][2]:
+        if os.environ.get("AVVAD_DP_TRACE"):
+            print("[dp] grad ready: param %s shape %s -> bucket %d pending %d/%d" % (self._names.get(id(p), "?"), tuple(p.shape), b, self.pending[b], self.buckets[b][2]), flush=True)
+        if self.pending[b] == self.buckets[b][2] and not os.environ.get("AVVAD_DP_LATE"):   # (debug aid: reduce everything in finish())
             self._launch(b)
 
     def _launch(self, b):
@@ -126,3 +137,4 @@ class BucketReducer:
         self.handles = []
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
+        self._seen = set()

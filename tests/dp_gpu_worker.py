@@ -27,6 +27,7 @@ def main():
     wave, video, target, lengths = [t.to(dev) for t in case.make_batch()]
     opt = FlatAdam(model.parameters(), lr=1e-3)
     red = avd.BucketReducer(opt.params, opt.flat_grad, opt.offsets, bucket_bytes=1 << 20)   # several buckets
+    red._names = {id(p_): n_ for n_, p_ in model.named_parameters()}
     lengths_s, wave_s, video_s, target_s = avd.shard_batch([lengths, wave, video, target], rank, world)
     y = model(wave_s, video_s, lengths_s)
     loss = batch_binary_cross_entropy(y, target_s, lengths_s, 1e-8)

@@ -231,7 +231,9 @@ def test_conv2d_fwd_dgrad_wgrad(N, H, W, C, Co, KS, stride, pad):
     dw = torch.empty(KS * KS * C, Co, device=DEV)
     L.check(lib.avvad_conv2d_wgrad(L.ptr(xd), L.ptr(gyd), L.ptr(dw), Ct.byref(d), st), "wgrad")
     ref_dw = w.grad.permute(2, 3, 1, 0).reshape(KS * KS * C, Co)
-    _report(tag + " wgrad", dw, ref_dw, 1e-4, 1e-5)
+    # (stem: the contraction runs over every output pixel of every frame; as ONE fp32 chain -- the whole-tile debug
+    #  schedule -- it drifts to 2.5e-4 on sums of magnitude 170, split-K partial sums stay under 1e-4)
+    _report(tag + " wgrad", dw, ref_dw, 3e-4 if C == 1 else 1e-4, 1e-5)
 
 
 # ------------------------------------------------------------------------------------------ trunk
@@ -573,11 +575,17 @@ def test_full_size_c4_dp_shard_gradient_sum():
     assert worst < 5e-3       # float-atomic split-K order differs between the three runs; a wrong shard sum would be O(1)
 
 
-def test_two_rank_gpu_data_parallel_step(tmp_path):
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_two_rank_gpu_data_parallel_step(tmp_path, monkeypatch, overlap):
     """The N > 1 path on the real kernels: two processes (both on cuda:0, gradients exchanged through gloo -- RCCL
     refuses two ranks per device), each a shard of the batch; the SUM all-reduce of the flat gradient must equal the
     single-process gradient of the whole batch (loss is a sum over sequences; eval-mode BatchNorm so that shards are
-    independent).  Exercises hooks + in-place gradient sinks + the side HIP stream + bucket launches together."""
+    independent).  Exercises hooks + in-place gradient sinks + the side HIP stream + bucket launches together.
+    Both sides run the whole-tile schedule (AVVAD_NO_STREAMK=all): a sample's forward is then bit-identical whatever
+    batch it sits in, so no ReLU decision can differ between the shard runs and the whole-batch run (with stream-K
+    the split points move with the batch size, and one flipped unit moves this small model's gradient by 1e-2).
+    Both stream layouts are run: they change the order in which gradients become ready, and with it which bucket
+    launches when (overlap=0 exposed a double-counted readiness signal that reduced a bucket too early)."""
     import socket
     import subprocess
     import sys
@@ -588,6 +596,8 @@ def test_two_rank_gpu_data_parallel_step(tmp_path):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     out = str(tmp_path / "flat_grad.pt")
+    monkeypatch.setenv("AVVAD_NO_STREAMK", "all")
+    monkeypatch.setenv("AVVAD_OVERLAP", overlap)
     env = dict(os.environ, AVVAD_DIST_BACKEND="gloo", AVVAD_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_gpu_worker.py"), out]
@@ -608,4 +618,4 @@ def test_two_rank_gpu_data_parallel_step(tmp_path):
     ref = opt.flat_grad.detach().cpu()
     rel = float((got - ref).norm() / ref.norm())
     print("two-rank DP: |flat grad| %.4e, relL2(all-reduced shards vs whole batch) %.2e" % (float(ref.norm()), rel))
-    assert float(ref.norm()) > 0 and rel < 5e-3      # stream-K atomic order differs between the runs; a wrong exchange is O(1)
+    assert float(ref.norm()) > 0 and rel < 1e-4      # only the order of the sum over samples differs; a wrong exchange is O(1)
