@@ -7,6 +7,7 @@ WCFG = dict(filter_width=2, quantization_channel=1, dilations=[1, 2, 4, 8], en_r
             en_bottleneck_width=64, en_pool_kernel_size=8, use_bias=True)
 RF = 16          # 1 + sum(dilations)
 N_SEQ, T, HOP = 4, 8, 32
+SGD_LR = 0.05
 
 
 def make_model():
