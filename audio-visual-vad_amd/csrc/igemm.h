@@ -197,7 +197,9 @@ struct Stage {
 // pipe is arbitrated oldest-first); XCDs finish up to 17 % apart on equal shares (the same two are slowest for every
 // shape on a given device).  Tried and dropped: age-skewed shares (+-1 %), a dynamically pulled tail pool of 8-K-tile
 // pieces (1-5 % slower: every piece pays a prologue and a 64 KB atomic flush), K-major cells for the weight gradients
-// (less HBM traffic, 2 % slower end to end), staggering the co-residents' phases (no effect).
+// (less HBM traffic, 2 % slower end to end), staggering the co-residents' phases (no effect), requesting the NEXT
+// segment's first K tile before the epilogue (the prefetched registers live across the epilogue: past the 128-VGPR
+// budget of 4 waves/SIMD the 8-wave kernels spill, 5 % slower end to end).
 // NTH = 256: 4 waves as 2x2, each (BM/2)x(BN/2);  NTH = 512: 8 waves as 2x4, each (BM/2)x(BN/4) -- half the
 // accumulators and staging registers per wave, so twice the waves per SIMD fit next to the same LDS tile.
 template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi>
