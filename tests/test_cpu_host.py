@@ -224,3 +224,26 @@ def test_direct_gradient_sinks_notify_the_reducer():
         assert ops._grad_target(ps[0], False) == (None, False)
     finally:
         ops.GRAD_SINKS.remove(seen.append) if seen.append in ops.GRAD_SINKS else ops.GRAD_SINKS.clear()
+
+
+def test_bucket_reducer_counts_each_parameter_once_per_step():
+    """A parameter whose gradient is written in place can be announced twice (in-place sink + autograd's
+    post-accumulate hook): the second announcement must not count, or a bucket is reduced before its last gradients
+    exist; finish() re-arms the bookkeeping for the next step."""
+    from avvad import dist as avd
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(6)), torch.nn.Parameter(torch.randn(2))]
+    flat, offsets = avd.flat_views(ps)
+    red = avd.BucketReducer(ps, flat, offsets, bucket_bytes=1 << 30)        # world size 1: one bucket, nothing is sent
+    assert len(red.buckets) == 1 and red.buckets[0][2] == 3
+    launched = []
+    red._launch = lambda b: launched.append(b)
+    red._on_grad(ps[0]); red._on_grad(ps[0]); red._on_grad(ps[1]); red._on_grad(ps[1])
+    assert red.pending[0] == 2 and launched == []
+    red._on_grad(ps[2])
+    assert red.pending[0] == 3 and launched == [0]
+    red._on_grad(ps[2])
+    assert launched == [0]
+    red.finish()
+    assert red.pending == [0] and not red._seen
+    red._on_grad(ps[0])
+    assert red.pending[0] == 1
