@@ -78,11 +78,14 @@ class LstmDesc(C.Structure):
 SIGNATURES = {
     "avvad_version": (C.c_char_p, []),
     "avvad_abi_version": (C.c_int, []),
+    "avvad_set_option": (C.c_int, [C.c_char_p, C.c_int]),
+    "avvad_get_option": (C.c_int, [C.c_char_p]),
     "avvad_gemm_f32": (C.c_int, [FP, FP, FP, FP, C.POINTER(GemmDesc), FP]),
     "avvad_wavenet_workspace": (C.c_size_t, [C.POINTER(WavenetDesc)]),
     "avvad_wavenet_fwd": (C.c_int, [FP, C.POINTER(WavenetPtrs), FP, C.POINTER(WavenetDesc), FP, C.c_size_t, FP]),
     "avvad_wavenet_bwd": (C.c_int, [FP, C.POINTER(WavenetPtrs), FP, C.POINTER(WavenetPtrs), FP,
                                     C.POINTER(WavenetDesc), FP, C.c_size_t, FP]),
+    "avvad_wavenet_block_fwd": (C.c_int, [FP, FP, FP, FP, FP, FP, C.c_int, C.c_int, C.c_int, FP]),
     "avvad_conv2d_pack_weights": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
     "avvad_conv2d_fwd": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
     "avvad_conv2d_dgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), C.c_int, FP]),
@@ -97,8 +100,16 @@ SIGNATURES = {
     "avvad_mcb_workspace": (C.c_size_t, [C.POINTER(McbDesc)]),
     "avvad_mcb_fusion_fwd": (C.c_int, [FP] * 11 + [C.POINTER(McbDesc), FP, C.c_size_t, FP]),
     "avvad_mcb_fusion_bwd": (C.c_int, [FP] * 12 + [C.POINTER(McbDesc), FP, C.c_size_t, FP]),
+    "avvad_count_sketch_fwd": (C.c_int, [FP, FP, FP, FP, C.c_int, C.c_int, C.c_int, FP]),
+    "avvad_count_sketch_bwd": (C.c_int, [FP, FP, FP, FP, C.c_int, C.c_int, C.c_int, FP]),
+    "avvad_mcb_fwd": (C.c_int, [FP] * 7 + [C.c_int] * 4 + [FP]),
+    "avvad_mcb_bwd": (C.c_int, [FP] * 9 + [C.c_int] * 4 + [FP]),
     "avvad_stft_workspace": (C.c_size_t, [C.POINTER(StftDesc)]),
     "avvad_stft": (C.c_int, [FP, FP, C.POINTER(StftDesc), C.c_int, FP, C.c_size_t, FP]),
+    "avvad_stft_features": (C.c_int, [FP, FP, FP, FP, C.POINTER(StftDesc), C.c_float, FP, C.c_size_t, FP]),
+    "avvad_peak_normalize": (C.c_int, [FP, FP, C.c_int, C.c_long, FP]),
+    "avvad_standardize": (C.c_int, [FP, FP, FP, FP, C.c_size_t, C.c_int, C.c_int, C.c_float, FP]),
+    "avvad_bce_2classes": (C.c_int, [FP, FP, FP, FP, FP, FP, C.c_long, C.c_int, C.c_float, FP]),
     "avvad_bce_masked": (C.c_int, [FP, FP, FP, FP, FP, C.c_int, C.c_int, C.c_int, C.c_float, FP]),
     "avvad_adam_step": (C.c_int, [FP, FP, FP, FP, C.c_size_t, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int, FP]),
     "avvad_copy_cols": (C.c_int, [FP, FP, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, FP]),
@@ -124,6 +135,15 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def set_option(name, value):
+    """Process-wide schedule option of the library (include/avvad.h: avvad_set_option)."""
+    check(lib().avvad_set_option(name.encode(), int(value)), "avvad_set_option(%s)" % name)
+
+
+def get_option(name):
+    return lib().avvad_get_option(name.encode())
 
 
 def check(rc, what):

@@ -62,36 +62,72 @@ def flat_views(params):
 class BucketReducer:
     """params: trainable parameters whose ``.grad`` are views into ``flat_grad`` at ``offsets`` (elements).
     Buckets are contiguous ranges of the flat buffer of about ``bucket_bytes`` (xGMI is point-to-point:
-    few large messages beat many small ones; 25 MB keeps a ring step well above the latency floor)."""
+    few large messages beat many small ones; 25 MB keeps a ring step well above the latency floor).
 
-    def __init__(self, params, flat_grad, offsets, bucket_bytes=25 << 20, group=None):
+    The flat buffer is laid out in forward (registration) order and backward produces gradients in reverse, so buckets
+    complete from the END of the buffer towards its start.  With ``names`` (``model.named_parameters()`` order) a bucket
+    is also closed where the top-level sub-module changes (``features`` | ``wavenet_en`` | ``lstm_*`` | ``vad_*``) once
+    it holds ``min_group_bytes``: the head's buckets then never wait for trunk gradients and overlap the whole trunk
+    backward.  Parameters that received no gradient in the previous step (the reference's unused ``bn`` of
+    ``AV_Net.py:33``, frozen sub-modules) are dropped from the readiness count, so their bucket still launches from the
+    hooks instead of from ``finish()``."""
+
+    def __init__(self, params, flat_grad, offsets, bucket_bytes=25 << 20, group=None, names=None, min_group_bytes=4 << 20):
         self.flat_grad = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        self.buckets = []          # (start, end, n_params)
+        self.params = list(params)             # keep the objects alive: the maps below are keyed by id()
+        self.buckets = []                      # (start, end, n_params)
         self.param_bucket = {}
+        tops = [n.split(".")[0] for n in names] if names is not None else None
         start, count = 0, 0
-        for i, p in enumerate(params):
+        for i, p in enumerate(self.params):
             end = offsets[i + 1]
             count += 1
             self.param_bucket[id(p)] = len(self.buckets)
-            if (end - start) * 4 >= bucket_bytes or i == len(params) - 1:
+            size = (end - start) * 4
+            last = i == len(self.params) - 1
+            group_edge = tops is not None and not last and tops[i + 1] != tops[i] and size >= min_group_bytes
+            if size >= bucket_bytes or group_edge or last:
                 self.buckets.append((start, end, count))
                 start, count = end, 0
+        self.expected = [b[2] for b in self.buckets]    # parameters a bucket waits for (absent ones removed)
+        self.absent = set()                    # id(p) of parameters that got no gradient last step
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.handles = []
         self._hooks = []
-        self._names = {}
+        self._names = dict(zip(map(id, self.params), names)) if names is not None else {}
         self._seen = set()
+        self._sink = None
+        self._trace = bool(os.environ.get("AVVAD_DP_TRACE"))      # debug aids, read once
+        self._late = bool(os.environ.get("AVVAD_DP_LATE"))
         if self.world > 1:
-            for p in params:
+            for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             try:                      # gradients written in place by the HIP backward bypass autograd's hooks
                 from . import ops
-                ops.GRAD_SINKS.append(self._on_grad)
+                self._sink = self._on_grad
+                ops.GRAD_SINKS.append(self._sink)
             except ImportError:       # CPU-only use of the reducer (gloo tests)
                 pass
+
+    def close(self):
+        """Detach from autograd and from the HIP backward's gradient sinks (a process may build several reducers)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if self._sink is not None:
+            from . import ops
+            if self._sink in ops.GRAD_SINKS:
+                ops.GRAD_SINKS.remove(self._sink)
+            self._sink = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _on_grad(self, p):
         """A parameter's gradient for this step is complete (all kernels that write it are enqueued).  Called by
@@ -99,15 +135,23 @@ class BucketReducer:
         announced by BOTH (observed on torch 2.10: the hook also fires for the ``None`` the Function returns), so
         repeats within a step are dropped -- counting them launched a bucket's all-reduce before its last gradients
         existed (caught by tests/test_gpu_parity.py::test_two_rank_gpu_data_parallel_step).  Assumes what holds for these
-        models: every parameter is written by exactly one backward Function per step."""
+        models: every parameter is written by exactly one backward Function per step (no gradient accumulation over
+        several backward() calls between two finish() calls: that raises below instead of reducing too early)."""
         if id(p) not in self.param_bucket or id(p) in self._seen:
             return
         self._seen.add(id(p))
         b = self.param_bucket[id(p)]
+        if id(p) in self.absent:               # came back (e.g. unfrozen): wait for it again from now on
+            self.absent.discard(id(p))
+            self.expected[b] += 1
+        if self.launched[b]:
+            raise RuntimeError("BucketReducer: gradient of %s announced after its bucket was all-reduced (a parameter that "
+                               "had no gradient in the previous step got one now, or backward() ran twice before finish())"
+                               % self._names.get(id(p), tuple(p.shape)))
         self.pending[b] += 1
-        if os.environ.get("AVVAD_DP_TRACE"):
-            print("[dp] grad ready: param %s shape %s -> bucket %d pending %d/%d" % (self._names.get(id(p), "?"), tuple(p.shape), b, self.pending[b], self.buckets[b][2]), flush=True)
-        if self.pending[b] == self.buckets[b][2] and not os.environ.get("AVVAD_DP_LATE"):   # (debug aid: reduce everything in finish())
+        if self._trace:
+            print("[dp] grad ready: param %s shape %s -> bucket %d pending %d/%d" % (self._names.get(id(p), "?"), tuple(p.shape), b, self.pending[b], self.expected[b]), flush=True)
+        if self.pending[b] == self.expected[b] and not self._late:
             self._launch(b)
 
     def _launch(self, b):
@@ -134,6 +178,11 @@ class BucketReducer:
                 self._launch(b)
             for h in self.handles:
                 h.wait()
+            # parameters nobody announced this step stop counting towards their bucket's readiness
+            for p in self.params:
+                if id(p) not in self._seen and id(p) not in self.absent:
+                    self.absent.add(id(p))
+                    self.expected[self.param_bucket[id(p)]] -= 1
         self.handles = []
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)

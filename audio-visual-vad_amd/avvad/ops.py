@@ -5,6 +5,7 @@ every arithmetic step of the hot path runs in the HIP kernels.  All tensors
 must be fp32, contiguous and live on the GPU -- anything else raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -18,12 +19,15 @@ def _stream():
 _SIDE = {}
 
 
+_SIDE_PRIO = int(os.environ.get("AVVAD_SIDE_PRIO", "-1"))      # read once at import
+_OVERLAP = os.environ.get("AVVAD_OVERLAP", "1") != "0"
+
+
 def side_stream():
     """The per-device side HIP stream on which independent sub-graphs (the audio encoder) run next to the main one."""
     dev = torch.cuda.current_device()
     if dev not in _SIDE:
-        import os
-        _SIDE[dev] = torch.cuda.Stream(device=dev, priority=int(os.environ.get("AVVAD_SIDE_PRIO", "-1")))
+        _SIDE[dev] = torch.cuda.Stream(device=dev, priority=_SIDE_PRIO)
     return _SIDE[dev]
 
 
@@ -32,8 +36,13 @@ def side_streams():
 
 
 def overlap_enabled():
-    import os
-    return os.environ.get("AVVAD_OVERLAP", "1") != "0"
+    return _OVERLAP
+
+
+def set_overlap(flag):
+    """Run the audio encoder on the side stream (True, default) or in line on the current stream."""
+    global _OVERLAP
+    _OVERLAP = bool(flag)
 
 
 def _dev(t, name):
@@ -348,7 +357,95 @@ class McbFusionFn(torch.autograd.Function):
         return da, dv, None, None, None, None, dw, db, None, None, None, None, None
 
 
+class CountSketchFn(torch.autograd.Function):
+    """psi(x, h, s): out[..., h[i]] += s[i] x[..., i]  (compact_bilinear_pooling.py:7-27,41-57)."""
+
+    @staticmethod
+    def forward(ctx, h, s, output_size, x):
+        x = _dev(x, "x")
+        if not h.is_cuda or h.dtype != torch.long:
+            raise L.AvvadError("h must be an int64 GPU tensor")
+        In = x.shape[-1]
+        rows = x.numel() // In
+        out = torch.empty(x.shape[:-1] + (output_size,), dtype=torch.float32, device=x.device)
+        L.check(L.lib().avvad_count_sketch_fwd(L.ptr(x), L.ptr(h), L.ptr(_dev(s, "s")), L.ptr(out), rows, In, output_size,
+                                               _stream()), "avvad_count_sketch_fwd")
+        ctx.save_for_backward(h, s)
+        ctx.dims = (tuple(x.shape), rows, In, output_size)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h, s = ctx.saved_tensors
+        shape, rows, In, D = ctx.dims
+        dx = torch.empty(shape, dtype=torch.float32, device=dout.device)
+        L.check(L.lib().avvad_count_sketch_bwd(L.ptr(_dev(dout, "dout")), L.ptr(h), L.ptr(s), L.ptr(dx), rows, In, D, _stream()),
+                "avvad_count_sketch_bwd")
+        return None, None, None, dx
+
+
+class CompactBilinearPoolingFn(torch.autograd.Function):
+    """psi(x,h1,s1) (*) psi(y,h2,s2): the raw pooled vector (compact_bilinear_pooling.py:140-220)."""
+
+    @staticmethod
+    def forward(ctx, h1, s1, h2, s2, output_size, x, y):
+        x, y = _dev(x, "x"), _dev(y, "y")
+        if x.shape[:-1] != y.shape[:-1]:
+            raise L.AvvadError("compact bilinear pooling: leading dimensions differ")
+        for t, n in ((h1, "h1"), (h2, "h2")):
+            if not t.is_cuda or t.dtype != torch.long:
+                raise L.AvvadError("%s must be an int64 GPU tensor" % n)
+        A, V = x.shape[-1], y.shape[-1]
+        rows = x.numel() // A
+        out = torch.empty(x.shape[:-1] + (output_size,), dtype=torch.float32, device=x.device)
+        L.check(L.lib().avvad_mcb_fwd(L.ptr(x), L.ptr(y), L.ptr(h1), L.ptr(_dev(s1, "s1")), L.ptr(h2), L.ptr(_dev(s2, "s2")),
+                                      L.ptr(out), rows, A, V, output_size, _stream()), "avvad_mcb_fwd")
+        ctx.save_for_backward(h1, s1, h2, s2, x, y)
+        ctx.dims = (rows, A, V, output_size)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        h1, s1, h2, s2, x, y = ctx.saved_tensors
+        rows, A, V, D = ctx.dims
+        dx = torch.empty_like(x) if ctx.needs_input_grad[5] else None
+        dy = torch.empty_like(y) if ctx.needs_input_grad[6] else None
+        L.check(L.lib().avvad_mcb_bwd(L.ptr(x), L.ptr(y), L.ptr(h1), L.ptr(s1), L.ptr(h2), L.ptr(s2), L.ptr(_dev(dout, "dout")),
+                                      L.ptr(dx), L.ptr(dy), rows, A, V, D, _stream()), "avvad_mcb_bwd")
+        return None, None, None, None, None, dx, dy
+
+
 # --------------------------------------------------------------------------- loss
+class Bce2ClassesFn(torch.autograd.Function):
+    """-mean(sum(x log(r1+eps) + (1-x) log(r2+eps), dim=-1))  (models/utils.py:115-116), r1/r2 probabilities."""
+
+    @staticmethod
+    def forward(ctx, r1, r2, x, eps):
+        r1, r2 = _dev(r1, "r1"), _dev(r2, "r2")
+        x = _dev(x.to(torch.float32), "x")
+        if r1.shape != r2.shape or r1.shape != x.shape:
+            raise L.AvvadError("binary_cross_entropy_2classes: r1, r2, x must have the same shape")
+        Y = r1.shape[-1]
+        rows = r1.numel() // Y
+        loss = torch.empty(1, dtype=torch.float32, device=r1.device)
+        d1, d2 = torch.empty_like(r1), torch.empty_like(r2)
+        L.check(L.lib().avvad_bce_2classes(L.ptr(r1), L.ptr(r2), L.ptr(x), L.ptr(loss), L.ptr(d1), L.ptr(d2), rows, Y, float(eps),
+                                           _stream()), "avvad_bce_2classes")
+        ctx.save_for_backward(d1, d2)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        out = []
+        for g in ctx.saved_tensors:
+            g = g.clone()
+            L.check(L.lib().avvad_scale_by_device_scalar(L.ptr(g), L.ptr(_dev(dloss, "dloss").view(1)), g.numel(), _stream()),
+                    "avvad_scale_by_device_scalar")
+            out.append(g)
+        return out[0], out[1], None, None
+
+
+
 class MaskedBceFn(torch.autograd.Function):
     """sum_b mean_{t<len_b} BCE-with-eps(logits, targets)  (models/utils.py:108-113 + train_AV_net.py:298-301)."""
 
@@ -441,8 +538,10 @@ def n_frames(L, n_fft, hop, pad_at_end=True, fs=16e3):
     return (L - n_fft) // hop + 1
 
 
-def stft(wave, n_fft=1024, hop=256, mode=0, eps=1e-8, pad_at_end=True, fs=16e3):
-    """wave (B,L) or (L,) on the GPU.  mode 0: log-power (B,T,F); 1: power (B,T,F); 2: legacy real view (F,T,2)."""
+def stft(wave, n_fft=1024, hop=256, mode=0, eps=1e-8, pad_at_end=True, fs=16e3, mean=None, std=None, norm_eps=1e-8):
+    """wave (B,L) or (L,) on the GPU.  mode 0: log-power (B,T,F); 1: power (B,T,F); 2: legacy real view (F,T,2).
+    With ``mean`` / ``std`` (F values each, mode 0) the train-set standardisation (x - mean) / (std + norm_eps) of the
+    evaluate scripts is applied in the same pass (avvad_stft_features)."""
     w = _dev(wave, "wave")
     w2 = w.view(1, -1) if w.dim() == 1 else w
     B, Ls = w2.shape
@@ -451,5 +550,38 @@ def stft(wave, n_fft=1024, hop=256, mode=0, eps=1e-8, pad_at_end=True, fs=16e3):
     d = L.StftDesc(B, Ls, n_fft, hop, T, float(eps))
     ws = _ws(L.lib().avvad_stft_workspace(C.byref(d)), w.device)
     out = torch.empty((F, T, 2) if mode == 2 else (B, T, F), dtype=torch.float32, device=w.device)
+    if mean is not None:
+        if mode != 0 or std is None:
+            raise L.AvvadError("standardisation is fused into the log-power mode only and needs both mean and std")
+        mean, std = _dev(mean, "mean").reshape(-1), _dev(std, "std").reshape(-1)
+        if mean.numel() != F or std.numel() != F:
+            raise L.AvvadError("mean / std must hold %d values" % F)
+        L.check(L.lib().avvad_stft_features(L.ptr(w2), L.ptr(mean), L.ptr(std), L.ptr(out), C.byref(d), float(norm_eps), L.ptr(ws),
+                                            ws.numel() * 4, _stream()), "avvad_stft_features")
+        return out
     L.check(L.lib().avvad_stft(L.ptr(w2), L.ptr(out), C.byref(d), mode, L.ptr(ws), ws.numel() * 4, _stream()), "avvad_stft")
+    return out
+
+
+def peak_normalize(wave):
+    """x / max|x| per utterance (evaluate_audio_net.py:125-127); wave (B,L) or (L,)."""
+    w = _dev(wave, "wave")
+    w2 = w.view(1, -1) if w.dim() == 1 else w
+    out = torch.empty_like(w2)
+    L.check(L.lib().avvad_peak_normalize(L.ptr(w2), L.ptr(out), w2.shape[0], w2.shape[1], _stream()), "avvad_peak_normalize")
+    return out.view(w.shape)
+
+
+def standardize(x, mean, std, eps=1e-8):
+    """(x - mean.T) / (std + eps).T of the train / evaluate loops (train_AV_net.py:286-291).  ``mean`` / ``std`` hold
+    either one value per feature of the last axis (audio: (513,1)) or a single value (video: (1,1))."""
+    x = _dev(x, "x")
+    mean, std = _dev(mean, "mean").reshape(-1), _dev(std, "std").reshape(-1)
+    F = x.shape[-1]
+    nstat = mean.numel()
+    if std.numel() != nstat or nstat not in (1, F):
+        raise L.AvvadError("standardize: statistics must hold 1 or %d values, got %d / %d" % (F, nstat, std.numel()))
+    out = torch.empty_like(x)
+    L.check(L.lib().avvad_standardize(L.ptr(x), L.ptr(mean), L.ptr(std), L.ptr(out), x.numel() // F, F, nstat, float(eps),
+                                      _stream()), "avvad_standardize")
     return out

@@ -23,6 +23,24 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // our launches only sees our launches.
 #define AVVAD_ENTER() (void)hipGetLastError()
 
+// Process-wide schedule options (tuning / debugging switches).  They are NOT read from the environment per launch: the
+// table is filled once, on first use, from the AVVAD_* variables and can afterwards only be changed through the C ABI
+// (avvad_set_option).  Defined in misc.hip.
+struct AvvadTune {
+  int igemm_variant;        // -1 default; 0 "db" 4-wave double LDS buffer, 1 "sb" single buffer, 2 "w8" 8 waves
+  int no_streamk;           // 0 production; 1 whole-tile schedule for every GEMM; 10+m only for epilogue mode m
+  int kmajor;               // K-major cells for the conv weight gradients
+  int lstm_no_fused_step;   // per-step GEMM + gate kernel instead of the fused recurrent step
+  int lstm_no_persistent;   // one launch per time step instead of the persistent recurrent kernel
+  int no_stem_kernel;       // 7x7 stem on the engine instead of the LDS-resident frame kernel
+  int no_tall;              // 128x64 tiles instead of 256x64 for the 64-channel convolutions
+  int wn_no_fused_tail;     // unfused encoder tail backward
+  int wn_no_fused_wgrad;    // unfused encoder block backward (dz, weight gradients as separate kernels)
+  int wn_no_group;          // layer-at-a-time encoder (no LDS-fused small-dilation groups)
+  int max_cus;              // cap on the CUs a persistent grid occupies (0 = all 256): leaves room for RCCL kernels
+};
+AvvadTune& avvad_tune();
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

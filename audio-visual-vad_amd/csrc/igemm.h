@@ -22,7 +22,6 @@
 //              global loads go straight to 16-byte LDS stores.
 #pragma once
 #include "common.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace igemm {
@@ -462,10 +461,11 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   const int ktiles = (K + BK - 1) / BK;
   const long ntiles = (long)cdiv(M, BM) * cdiv(N, BN);
   const long iters = ntiles * ktiles;
-  const char* var = getenv("AVVAD_IGEMM_VARIANT");  // tuning aid: "db"/"sb" = 4-wave double/single LDS buffer, "w8" = 8 waves
+  const AvvadTune& tn = avvad_tune();
+  const int var = tn.igemm_variant;  // tuning aid: 0/1 = 4-wave double/single LDS buffer, 2 = 8 waves
   constexpr bool BIG = (BM == 128 && BN == 128);
   constexpr bool TALL = (BM == 256);             // 256x64, 8 waves as 4x2, single LDS buffer (41.6 KB), 2 workgroups / CU
-  const int variant = TALL ? 3 : (var ? (var[0] == 'd' ? 0 : (var[0] == 's' ? 1 : 2)) : (BIG ? 2 : 1));
+  const int variant = TALL ? 3 : (var >= 0 ? var : (BIG ? 2 : 1));
   // resident workgroups per CU (LDS footprint / VGPR budget of the instantiation)
   int per_cu;
   if (variant == 3) per_cu = 2;
@@ -473,14 +473,13 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   else if (variant == 1 || !BIG) per_cu = BIG ? 3 : (BM * BN >= 128 * 64 ? 4 : 6);
   else per_cu = 2;
   long G = (long)NUM_CU * per_cu;
-  const char* nsk = getenv("AVVAD_NO_STREAMK");   // debugging aid: "all", or the epilogue mode digit to restrict
-  const bool no_sk = nsk && (nsk[0] == 'a' || nsk[0] - '0' == e.mode);
+  const bool no_sk = tn.no_streamk == 1 || tn.no_streamk == 10 + e.mode;   // debugging aid: whole-tile schedule
   long full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
   int kchunks = 0;
   // OFF by default (AVVAD_KMAJOR=1 turns it on): it removes most of the wgrad kernel's beyond-L2 fetches, but the
   // kernels are MFMA-bound -- isolated they time the same (+-2 %), and the whole training step measured 0.45 ms
   // (2 %) SLOWER in three A/B/A/B pairs on one device (23.7 vs 23.25 ms), so tile-major stream-K stays the default.
-  if (split_k_hint > 1 && e.mode == 2 && ntiles <= G && getenv("AVVAD_KMAJOR")) {
+  if (split_k_hint > 1 && e.mode == 2 && ntiles <= G && tn.kmajor) {
     // r cells per worker (r = 1 or 2): kchunks = floor(r*G / ntiles); cost in K-tile iterations incl. ~8 per atomic flush
     long best = -1;
     for (int r = 1; r <= 2; ++r) {
@@ -503,9 +502,7 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
         const long cap = iters / 4 > 0 ? iters / 4 : 1;
         if (G > cap) G = cap;
       }
-      // (AVVAD_SKIP_ZERO: timing aid for bench.py's roofline probe, which wants the GEMM kernel's own duration --
-      // the zero-fill is a separate kernel with its own line in the rocprof summary; results are garbage with it set)
-      if (e.mode == 0 && !getenv("AVVAD_SKIP_ZERO")) {  // split pieces are atomically added: their tiles must start at zero
+      if (e.mode == 0) {  // split pieces are atomically added: their tiles must start at zero
         // only the stream-K round's tiles (the last `rem`, in row-major tile order) are added to; the tile rows from the
         // first of them down cover them -- the data-parallel tiles caught in that band are overwritten by plain stores
         const long row0 = (full_rounds * G / cdiv(N, BN)) * BM;

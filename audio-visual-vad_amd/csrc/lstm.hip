@@ -228,7 +228,7 @@ extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const flo
   if ((rc = avvad_gemm_impl(x, w_ih, w.bias, w.G, &gd, s))) return rc;
   const int split = pick_split(B, 4 * H, H);
   const bool fused_step = (B == 16 || B == 32 || B == 64 || B == 128 || B == 256) && (H % (16 * (256 / B)) == 0) &&
-                          !getenv("AVVAD_LSTM_NO_FUSED_STEP");
+                          !avvad_tune().lstm_no_fused_step;
   for (int t = 0; t < T; ++t) {
     if (t > 0 && fused_step) {
       hipLaunchKernelGGL(lstm_step_fwd_mfma, dim3(H / 4), dim3(1024), 0, s, w.G, w.Cs, y, w_hh, d->lengths, B, T, H, t);

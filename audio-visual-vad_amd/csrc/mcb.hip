@@ -121,6 +121,30 @@ __global__ void ssqrt_bwd(const float* __restrict__ y, const double* __restrict_
   }
 }
 
+// Stand-alone count sketch (CountSketch.forward, compact_bilinear_pooling.py:7-27): out[row][h[i]] += s[i] x[row][i].
+// One workgroup per row, the D buckets in LDS (same accumulation as sketch_row inside the fused kernels).
+__global__ void __launch_bounds__(256)
+    count_sketch_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ h, const float* __restrict__ s,
+                            float* __restrict__ out, int In, int D) {
+  __shared__ float p[MAXD];
+  const int row = blockIdx.x;
+  for (int j = threadIdx.x; j < D; j += 256) p[j] = 0.f;
+  __syncthreads();
+  sketch_row(x + (long)row * In, h, s, In, p);
+  __syncthreads();
+  for (int j = threadIdx.x; j < D; j += 256) out[(long)row * D + j] = p[j];
+}
+// backward (CountSketchFn_backward, :30-38): dx[row][i] = s[i] * dout[row][h[i]]
+__global__ void count_sketch_bwd_kernel(const float* __restrict__ dout, const int64_t* __restrict__ h, const float* __restrict__ s,
+                                        float* __restrict__ dx, long rows, int In, int D) {
+  const long n = rows * In;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / In;
+    const int c = (int)(i - row * In);
+    dx[i] = s[c] * dout[row * D + (int)h[c]];
+  }
+}
+
 struct Ws {
   float *Y, *Z, *Y2, *G, *scale, *shift, *mean, *invstd, *coef;
   double *part, *sumsq;
@@ -210,6 +234,47 @@ extern "C" int avvad_mcb_fusion_bwd(const float* audio, const float* video, cons
   if (daudio || dvideo)
     hipLaunchKernelGGL(mcb_bwd_kernel, dim3(d->rows), dim3(256), 0, s, audio, video, h1, s1, h2, s2, w.G, daudio, dvideo, d->A,
                        d->V, d->D);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+// ---------------------------------------------------------------- stand-alone entry points (the bare modules of the reference)
+extern "C" int avvad_count_sketch_fwd(const float* x, const int64_t* h, const float* sg, float* out, int rows, int In, int D,
+                                      avvad_stream_t sv) {
+  AVVAD_ENTER();
+  if (!x || !h || !sg || !out || rows <= 0 || In <= 0 || D <= 0 || D > MAXD) return AVVAD_EINVAL;
+  hipLaunchKernelGGL(count_sketch_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)sv, x, h, sg, out, In, D);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_count_sketch_bwd(const float* dout, const int64_t* h, const float* sg, float* dx, int rows, int In, int D,
+                                      avvad_stream_t sv) {
+  AVVAD_ENTER();
+  if (!dout || !h || !sg || !dx || rows <= 0 || In <= 0 || D <= 0) return AVVAD_EINVAL;
+  hipLaunchKernelGGL(count_sketch_bwd_kernel, dim3(ew_grid((long)rows * In)), dim3(256), 0, (hipStream_t)sv, dout, h, sg, dx,
+                     (long)rows, In, D);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+// raw compact bilinear pooling vector y = psi(a) (*) psi(v) (circular convolution), no post-processing
+extern "C" int avvad_mcb_fwd(const float* a, const float* v, const int64_t* h1, const float* s1, const int64_t* h2,
+                             const float* s2, float* y, int rows, int A, int V, int D, avvad_stream_t sv) {
+  AVVAD_ENTER();
+  if (!a || !v || !h1 || !s1 || !h2 || !s2 || !y || rows <= 0 || A <= 0 || V <= 0 || D <= 0 || D > MAXD) return AVVAD_EINVAL;
+  hipLaunchKernelGGL(mcb_fwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)sv, a, v, h1, s1, h2, s2, y, A, V, D);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_mcb_bwd(const float* a, const float* v, const int64_t* h1, const float* s1, const int64_t* h2,
+                             const float* s2, const float* dy, float* da, float* dv, int rows, int A, int V, int D,
+                             avvad_stream_t sv) {
+  AVVAD_ENTER();
+  if (!a || !v || !h1 || !s1 || !h2 || !s2 || !dy || rows <= 0 || A <= 0 || V <= 0 || D <= 0 || D > MAXD) return AVVAD_EINVAL;
+  if (da || dv)
+    hipLaunchKernelGGL(mcb_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)sv, a, v, h1, s1, h2, s2, dy, da, dv, A, V, D);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

@@ -5,6 +5,60 @@ extern "C" const char* avvad_version(void) { return "avvad-hip 0.1 (gfx950, fp32
 extern "C" int avvad_abi_version(void) {
   AVVAD_ENTER(); return 1; }
 
+// ---------------------------------------------------------------- schedule options
+#include <stdlib.h>
+#include <string.h>
+namespace {
+struct OptName { const char* name; const char* env; int AvvadTune::*field; };
+const OptName kOpts[] = {
+    {"igemm_variant", "AVVAD_IGEMM_VARIANT", &AvvadTune::igemm_variant},
+    {"no_streamk", "AVVAD_NO_STREAMK", &AvvadTune::no_streamk},
+    {"kmajor", "AVVAD_KMAJOR", &AvvadTune::kmajor},
+    {"lstm_no_fused_step", "AVVAD_LSTM_NO_FUSED_STEP", &AvvadTune::lstm_no_fused_step},
+    {"lstm_no_persistent", "AVVAD_LSTM_NO_PERSISTENT", &AvvadTune::lstm_no_persistent},
+    {"no_stem_kernel", "AVVAD_NO_STEM_KERNEL", &AvvadTune::no_stem_kernel},
+    {"no_tall", "AVVAD_NO_TALL", &AvvadTune::no_tall},
+    {"wn_no_fused_tail", "AVVAD_WN_NO_FUSED_TAIL", &AvvadTune::wn_no_fused_tail},
+    {"wn_no_fused_wgrad", "AVVAD_WN_NO_FUSED_WGRAD", &AvvadTune::wn_no_fused_wgrad},
+    {"wn_no_group", "AVVAD_WN_NO_GROUP", &AvvadTune::wn_no_group},
+    {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
+};
+int parse_opt(const char* name, const char* v) {
+  if (!strcmp(name, "igemm_variant")) return v[0] == 'd' ? 0 : (v[0] == 's' ? 1 : (v[0] == 'w' ? 2 : atoi(v)));
+  if (!strcmp(name, "no_streamk")) return v[0] == 'a' ? 1 : (v[0] >= '0' && v[0] <= '9' && !v[1] ? 10 + (v[0] - '0') : atoi(v));
+  if (!strcmp(name, "max_cus")) return atoi(v);
+  return (v[0] && strcmp(v, "0")) ? 1 : 0;
+}
+}  // namespace
+
+AvvadTune& avvad_tune() {
+  static AvvadTune t = [] {      // the environment is read ONCE, here
+    AvvadTune x;
+    memset(&x, 0, sizeof(x));
+    x.igemm_variant = -1;
+    for (const OptName& o : kOpts) {
+      const char* v = getenv(o.env);
+      if (v && v[0]) x.*(o.field) = parse_opt(o.name, v);
+    }
+    return x;
+  }();
+  return t;
+}
+
+extern "C" int avvad_set_option(const char* name, int value) {
+  if (!name) return AVVAD_EINVAL;
+  for (const OptName& o : kOpts)
+    if (!strcmp(o.name, name)) { avvad_tune().*(o.field) = value; return AVVAD_OK; }
+  return AVVAD_EINVAL;
+}
+
+extern "C" int avvad_get_option(const char* name) {
+  if (!name) return AVVAD_EINVAL;
+  for (const OptName& o : kOpts)
+    if (!strcmp(o.name, name)) return avvad_tune().*(o.field);
+  return AVVAD_EINVAL;
+}
+
 namespace {
 
 // Masked BCE-with-eps, summed over sequences.
@@ -40,6 +94,59 @@ __global__ void __launch_bounds__(1024)
     __syncthreads();
   }
   if (tid == 0) loss[0] = sm[0];
+}
+
+// Two-output-unit BCE (binary_cross_entropy_2classes, packages/models/utils.py:115-116; imported by
+// scripts/train_video_net.py:18):  loss = -mean_rows( sum_y [ x log(r1 + eps) + (1 - x) log(r2 + eps) ] ),
+// r1 / r2 are PROBABILITIES.  Value and both gradients in one deterministic workgroup.
+__global__ void __launch_bounds__(1024)
+    bce_2classes_kernel(const float* __restrict__ r1, const float* __restrict__ r2, const float* __restrict__ x,
+                        float* __restrict__ loss, float* __restrict__ dr1, float* __restrict__ dr2, long rows, int Y, float eps) {
+  __shared__ float sm[1024];
+  const int tid = threadIdx.x;
+  const long n = rows * Y;
+  const float inv = 1.f / (float)rows;
+  float acc = 0.f;
+  for (long i = tid; i < n; i += 1024) {
+    const float a = r1[i], b = r2[i], t = x[i];
+    acc -= (t * logf(a + eps) + (1.f - t) * logf(b + eps)) * inv;
+    if (dr1) dr1[i] = -t / (a + eps) * inv;
+    if (dr2) dr2[i] = -(1.f - t) / (b + eps) * inv;
+  }
+  sm[tid] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (tid < o) sm[tid] += sm[tid + o];
+    __syncthreads();
+  }
+  if (tid == 0) loss[0] = sm[0];
+}
+
+// Input standardisation with the train-set statistics (scripts/train_AV_net.py:286-291, evaluate_audio_net.py:158-163):
+//   out[r][f] = (x[r][f] - mean[f % nstat]) / (std[f % nstat] + eps)     nstat = F (audio: 513 bins) or 1 (video scalar)
+__global__ void standardize_kernel(const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                   float* __restrict__ out, size_t n, int F, int nstat, float eps) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const int f = nstat == 1 ? 0 : (int)(i % F);
+    out[i] = (x[i] - mean[f]) / (stdv[f] + eps);
+  }
+}
+
+// x / max|x| per utterance (scripts/evaluate_audio_net.py:125-127): one workgroup per row
+__global__ void __launch_bounds__(1024) peak_normalize_kernel(const float* __restrict__ x, float* __restrict__ out, long L) {
+  __shared__ float sm[1024];
+  const float* xr = x + (long)blockIdx.x * L;
+  float* orow = out + (long)blockIdx.x * L;
+  float m = 0.f;
+  for (long i = threadIdx.x; i < L; i += 1024) m = fmaxf(m, fabsf(xr[i]));
+  sm[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sm[threadIdx.x] = fmaxf(sm[threadIdx.x], sm[threadIdx.x + o]);
+    __syncthreads();
+  }
+  const float peak = sm[0];
+  for (long i = threadIdx.x; i < L; i += 1024) orow[i] = xr[i] / peak;
 }
 
 // torch.optim.Adam semantics (no weight decay, no amsgrad): scripts/train_AV_net.py:238,306
@@ -108,6 +215,34 @@ extern "C" int avvad_bce_masked(const float* logits, const float* targets, const
   if (!logits || !targets || !lengths || !loss || B <= 0 || T <= 0 || Y <= 0) return AVVAD_EINVAL;
   hipLaunchKernelGGL(bce_masked_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, logits, targets, lengths, loss, dlogits, B, T,
                      Y, eps);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_bce_2classes(const float* r1, const float* r2, const float* x, float* loss, float* dr1, float* dr2,
+                                  long rows, int Y, float eps, avvad_stream_t s) {
+  AVVAD_ENTER();
+  if (!r1 || !r2 || !x || !loss || rows <= 0 || Y <= 0) return AVVAD_EINVAL;
+  hipLaunchKernelGGL(bce_2classes_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, r1, r2, x, loss, dr1, dr2, rows, Y, eps);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_standardize(const float* x, const float* mean, const float* stdv, float* out, size_t rows, int F, int nstat,
+                                 float eps, avvad_stream_t s) {
+  AVVAD_ENTER();
+  if (!x || !mean || !stdv || !out || F <= 0 || (nstat != 1 && nstat != F)) return AVVAD_EINVAL;
+  if (rows == 0) return AVVAD_OK;
+  hipLaunchKernelGGL(standardize_kernel, dim3(grid1(rows * F)), dim3(256), 0, (hipStream_t)s, x, mean, stdv, out, rows * (size_t)F,
+                     F, nstat, eps);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+extern "C" int avvad_peak_normalize(const float* x, float* out, int B, long L, avvad_stream_t s) {
+  AVVAD_ENTER();
+  if (!x || !out || B <= 0 || L <= 0) return AVVAD_EINVAL;
+  hipLaunchKernelGGL(peak_normalize_kernel, dim3(B), dim3(1024), 0, (hipStream_t)s, x, out, L);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

@@ -60,6 +60,19 @@ __global__ void power_log(const float* __restrict__ S, float* __restrict__ out, 
     out[i] = take_log ? logf(pw + eps) : pw;
   }
 }
+// the evaluate scripts' whole feature chain behind the DFT: log(re^2 + im^2 + eps) then the train-set standardisation
+// (x - mean[f]) / (std[f] + eps)  (scripts/evaluate_audio_net.py:141-163) in the same pass
+__global__ void power_log_standardize(const float* __restrict__ S, const float* __restrict__ mean, const float* __restrict__ stdv,
+                                      float* __restrict__ out, long M, int F, int ld, float eps, float norm_eps) {
+  const long n = M * F;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long m = i / F;
+    const int f = (int)(i - m * F);
+    const float2 c = *reinterpret_cast<const float2*>(S + m * ld + 2 * f);
+    const float v = logf(c.x * c.x + c.y * c.y + eps);
+    out[i] = (v - mean[f]) / (stdv[f] + norm_eps);
+  }
+}
 // legacy torch.stft real view of ONE utterance: out[f][t][{re,im}]
 __global__ void to_legacy_view(const float* __restrict__ S, float* __restrict__ out, int T, int F, int ld) {
   const long n = (long)T * F * 2;
@@ -86,10 +99,25 @@ extern "C" size_t avvad_stft_workspace(const avvad_stft_desc* d) {
   return (align_up((size_t)d->n_fft * ld, 64) + align_up((size_t)d->B * d->T * ld, 64)) * sizeof(float);
 }
 
+static int stft_impl(const float* wave, float* out, const avvad_stft_desc* d, int mode, const float* mean, const float* stdv,
+                     float norm_eps, void* wsv, size_t ws_bytes, avvad_stream_t sv);
+
 // mode 0: out [B][T][F] = log(|X|^2 + eps);  mode 1: out [B][T][F] = |X|^2;
 // mode 2 (B == 1): out [F][T][2] = legacy torch.stft real view (re, im)
 extern "C" int avvad_stft(const float* wave, float* out, const avvad_stft_desc* d, int mode, void* wsv, size_t ws_bytes,
                           avvad_stream_t sv) {
+  return stft_impl(wave, out, d, mode, nullptr, nullptr, 0.f, wsv, ws_bytes, sv);
+}
+
+// log-power features standardised with the train-set statistics in the DFT's epilogue pass
+extern "C" int avvad_stft_features(const float* wave, const float* mean, const float* stdv, float* out,
+                                   const avvad_stft_desc* d, float norm_eps, void* wsv, size_t ws_bytes, avvad_stream_t sv) {
+  if (!mean || !stdv) return AVVAD_EINVAL;
+  return stft_impl(wave, out, d, 0, mean, stdv, norm_eps, wsv, ws_bytes, sv);
+}
+
+static int stft_impl(const float* wave, float* out, const avvad_stft_desc* d, int mode, const float* mean, const float* stdv,
+                     float norm_eps, void* wsv, size_t ws_bytes, avvad_stream_t sv) {
   AVVAD_ENTER();
   if (!wave || !out || !wsv || !ok_desc(d) || mode < 0 || mode > 2 || (mode == 2 && d->B != 1)) return AVVAD_EINVAL;
   if (ws_bytes < avvad_stft_workspace(d)) return AVVAD_EWORKSPACE;
@@ -105,6 +133,9 @@ extern "C" int avvad_stft(const float* wave, float* out, const avvad_stft_desc* 
   int rc = igemm::launch<128, 128>(a, b, e, M, ld, d->n_fft, 1, s);
   if (rc) return rc;
   if (mode == 2) hipLaunchKernelGGL(to_legacy_view, dim3(grid1((long)d->T * F * 2)), dim3(256), 0, s, S, out, d->T, F, ld);
+  else if (mean)
+    hipLaunchKernelGGL(power_log_standardize, dim3(grid1((long)M * F)), dim3(256), 0, s, S, mean, stdv, out, (long)M, F, ld, d->eps,
+                       norm_eps);
   else hipLaunchKernelGGL(power_log, dim3(grid1((long)M * F)), dim3(256), 0, s, S, out, (long)M, F, ld, d->eps, mode == 0);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;

@@ -239,7 +239,7 @@ __global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __r
 
 // stem backward of pool+relu: g0[n,h,w,c] = sum over pooled windows whose max is this element of dp0
 // (the max is recomputed with the identical expression, so equality is exact; zero ties carry no
-// gradient through the ReLU anyway).
+// gradient through the ReLU anyway; positive ties go to the first maximum in scan order, like torch).
 __global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
                                    const float* __restrict__ p0, const float* __restrict__ dp0, float* __restrict__ g0,
                                    int N, int Hc, int Wc, int Hp, int Wp) {
@@ -262,10 +262,27 @@ __global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __
         if (h < 2 * ph - 1 || h > 2 * ph + 1 || w < 2 * pw - 1 || w > 2 * pw + 1) continue;
         const long o = ((long)(n * Hp + ph) * Wp + pw) * 64 + q * 4;
         const float4 pm = *reinterpret_cast<const float4*>(p0 + o), dp = *reinterpret_cast<const float4*>(dp0 + o);
-        if (y[0] > 0.f && pm.x == y[0]) g[0] += dp.x;
-        if (y[1] > 0.f && pm.y == y[1]) g[1] += dp.y;
-        if (y[2] > 0.f && pm.z == y[2]) g[2] += dp.z;
-        if (y[3] > 0.f && pm.w == y[3]) g[3] += dp.w;
+        bool hit[4] = {y[0] > 0.f && pm.x == y[0], y[1] > 0.f && pm.y == y[1], y[2] > 0.f && pm.z == y[2],
+                       y[3] > 0.f && pm.w == y[3]};
+        if (hit[0] | hit[1] | hit[2] | hit[3]) {
+          // torch's max_pool2d keeps ONE argmax per window: the first maximum in row-major scan order (its update is a
+          // strict '>').  On an exact positive tie (flat image regions give identical conv outputs) only that element
+          // receives the gradient: drop this one if an EARLIER element of the window reaches the same maximum.
+          for (int hh = max(0, 2 * ph - 1); hh <= h; ++hh) {
+            const int wend = (hh == h) ? w - 1 : min(Wc - 1, 2 * pw + 1);
+            for (int ww = max(0, 2 * pw - 1); ww <= wend; ++ww) {
+              const float4 e = *reinterpret_cast<const float4*>(c0 + ((long)(n * Hc + hh) * Wc + ww) * 64 + q * 4);
+              if (fmaxf(bn_affine(e.x, sc.x, sh.x), 0.f) == pm.x) hit[0] = false;
+              if (fmaxf(bn_affine(e.y, sc.y, sh.y), 0.f) == pm.y) hit[1] = false;
+              if (fmaxf(bn_affine(e.z, sc.z, sh.z), 0.f) == pm.z) hit[2] = false;
+              if (fmaxf(bn_affine(e.w, sc.w, sh.w), 0.f) == pm.w) hit[3] = false;
+            }
+          }
+          if (hit[0]) g[0] += dp.x;
+          if (hit[1]) g[1] += dp.y;
+          if (hit[2]) g[2] += dp.z;
+          if (hit[3]) g[3] += dp.w;
+        }
       }
     reinterpret_cast<float4*>(g0)[i] = make_float4(g[0], g[1], g[2], g[3]);
   }
@@ -303,7 +320,7 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
   if (g.C == 1) {
     const int LDW = (g.W + 6) | 1;
     const size_t lds = (size_t)(g.H + 6) * LDW * sizeof(float);
-    if (g.KS == 7 && g.stride == 2 && g.pad == 3 && g.Co == 64 && lds <= 48 * 1024 && !getenv("AVVAD_NO_STEM_KERNEL")) {
+    if (g.KS == 7 && g.stride == 2 && g.pad == 3 && g.Co == 64 && lds <= 48 * 1024 && !avvad_tune().no_stem_kernel) {
       hipLaunchKernelGGL(stem_fwd_mfma, dim3(g.N), dim3(256), lds, s, x, wf, y, g.H, g.W, g.Ho, g.Wo, LDW);
       AVVAD_LAUNCH_CHECK();
       return AVVAD_OK;
@@ -317,7 +334,7 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
   const int T = g.KS * g.KS;
   convop::ColTapRows b{wf, g.Co, g.Co, K, g.C, T, convop::div_magic(T)};
   convop::Im2colFwd a{x, g, M, convop::tap_div(T, g.KS)};
-  if (g.Co <= 64) return getenv("AVVAD_NO_TALL") ? igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s) : igemm::launch<256, 64>(a, b, e, M, g.Co, K, 1, s);
+  if (g.Co <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s) : igemm::launch<256, 64>(a, b, e, M, g.Co, K, 1, s);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s);
 }
 // dx (+)= dgrad
@@ -359,7 +376,7 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
   const int T = g.KS * g.KS;
   convop::ColTapRows b{wd, g.C, g.C, K, g.Co, T, convop::div_magic(T)};
   convop::Im2colDgrad a{dy, g, M, convop::tap_div(T, g.KS)};
-  if (g.C <= 64) return getenv("AVVAD_NO_TALL") ? igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s) : igemm::launch<256, 64>(a, b, e, M, g.C, K, 1, s);
+  if (g.C <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s) : igemm::launch<256, 64>(a, b, e, M, g.C, K, 1, s);
   return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s);
 }
 // pk[(kh,kw,c)][co] = wgrad (pk zeroed here; split-K partials are added atomically)

@@ -891,8 +891,8 @@ __global__ void __launch_bounds__(256)
   if (i >= WG_SLAB) return;
   float s = 0.f;
   for (int b = blockIdx.y; b < nslab; b += gridDim.y) s += slab[(long)b * WG_SLAB + i];   // gridDim.y partial sums
-  if (i < 2048) atomicAdd(dW_dil + (i & 1023) * 2 + (i >> 10), s);
-  else if (i < 3072) atomicAdd(dW_dense + i - 2048, s);
+  if (i < 2048) { if (dW_dil) atomicAdd(dW_dil + (i & 1023) * 2 + (i >> 10), s); }   // every pointer may be NULL (frozen)
+  else if (i < 3072) { if (dW_dense) atomicAdd(dW_dense + i - 2048, s); }
   else if (i < 3104) { if (db_dil) atomicAdd(db_dil + i - 3072, s); }
   else if (db_dense) atomicAdd(db_dense + i - 3104, s);
 }
@@ -1024,6 +1024,21 @@ extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* 
   return AVVAD_OK;
 }
 
+// One residual block alone (the layer-at-a-time kernel the large dilations run on): what bench.py times per launch for
+// the HBM roofline entry, like avvad_conv2d_fwd for the MFMA one.
+extern "C" int avvad_wavenet_block_fwd(const float* s_in, const float* w_dil, const float* b_dil, const float* w_dense,
+                                       const float* b_dense, float* s_out, int B, int Lin, int dil, avvad_stream_t sv) {
+  AVVAD_ENTER();
+  if (!s_in || !w_dil || !w_dense || !s_out || B <= 0 || dil < 1 || Lin - dil < 1) return AVVAD_EINVAL;
+  const long ntiles = (long)B * cdiv(Lin - dil, 32);
+  long blocks = (ntiles + 3) / 4;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, (hipStream_t)sv, s_in, w_dil, b_dil, w_dense, b_dense,
+                     s_out, (float*)nullptr, B, Lin, dil);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
 extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* prm, const float* dout,
                                  const avvad_wavenet_grads* g, float* dwave, const avvad_wavenet_desc* d, void* wsv,
                                  size_t ws_bytes, avvad_stream_t sv) {
@@ -1043,7 +1058,7 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
   // ---- tail: dz_t = relu'(z) * pooled-grad ; d s_N = Wb^T dz_t
   float* DZT = ws + p.dzt;
   const bool tail_mfma = (R == 32 && Bn % 32 == 0 && Bn <= 1024);
-  const bool tail_fused = tail_mfma && Bn == 256 && g->bott_w && !getenv("AVVAD_WN_NO_FUSED_TAIL");
+  const bool tail_fused = tail_mfma && Bn == 256 && (g->bott_w || (d->use_bias && g->bott_b)) && !avvad_tune().wn_no_fused_tail;
   if (tail_fused) {
     // d s_N and the bottleneck's weight + bias gradients in one pass; dz_t is never materialised
     long blocks = ((long)B * cdiv(Lv, 32) + 3) / 4;
@@ -1089,7 +1104,10 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     if (fast) {
       // dz = (z>0) * W_dense^T dS ; then all four parameter gradients in one pass ; then d s_i
       long blocks = ((long)B * cdiv(Lo, 32) + 3) / 4;
-      if (g->dil_w_h[i] && g->dense_w_h[i] && !getenv("AVVAD_WN_NO_FUSED_WGRAD")) {
+      // a block's four parameter gradients are wanted independently (partially frozen blocks): the fused kernel always
+      // forms all four sums, the reduce skips the NULL destinations
+      const bool any_grad = g->dil_w_h[i] || g->dense_w_h[i] || (d->use_bias && (g->dil_b_h[i] || g->dense_b_h[i]));
+      if (any_grad && !avvad_tune().wn_no_fused_wgrad) {
         // dz AND the four parameter gradients in one pass over dS, Z and the two shifted s_i tiles
         long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave
         // one workgroup per CU is resident (368 VGPRs): ONE round of 256, not two of 512 -- every workgroup pays a weight
@@ -1109,7 +1127,7 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
                            (const float*)nullptr, (float*)nullptr, Zi, B, Li, dil);
         if (blocks > 768) blocks = 768;
         hipLaunchKernelGGL(wn_block_bwd_dz_mfma, dim3((int)blocks), dim3(256), 0, s, GA, Zi, prm->dense_w_h[i], DZ, B, Lo);
-        if (g->dil_w_h[i] && g->dense_w_h[i]) {
+        if (any_grad) {
           long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave
           if (wb > WG_MAXBLK) wb = WG_MAXBLK;
           if (wb < 1) wb = 1;

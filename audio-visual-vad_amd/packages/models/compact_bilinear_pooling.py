@@ -1,12 +1,15 @@
 """Drop-in containers for ``packages/models/compact_bilinear_pooling.py`` (``CountSketch`` ``:59-114``,
 ``CompactBilinearPooling`` ``:222-263``): same constructor arguments, buffers ``h`` (int64 bucket of each
 input channel) / ``s`` (+-1 sign) and sub-module names ``sketch1`` / ``sketch2`` so MCB checkpoints load.
-The fusion arithmetic (count sketch -> FFT circular convolution) is the next hot-path row:
-there is no HIP kernel for it yet and no fallback, so ``forward`` raises."""
+``forward`` of both modules runs the stand-alone HIP kernels (``avvad_count_sketch_fwd/bwd``,
+``avvad_mcb_fwd/bwd``: csrc/mcb.hip -- the FFT product of the reference is evaluated as the circular
+convolution it equals) and returns the raw sketch / pooled vector like the reference; inside ``DeepVAD_AV``
+the same arithmetic runs fused with the signed sqrt, L2 norm and BatchNorm1d (``ops.McbFusionFn``).
+GPU tensors only: there is no PyTorch fallback."""
 import torch
 import torch.nn as nn
 
-from avvad import AvvadError
+from avvad import ops
 
 
 class CountSketch(nn.Module):
@@ -30,7 +33,8 @@ class CountSketch(nn.Module):
         return self
 
     def forward(self, x):
-        raise AvvadError("CountSketch is a buffer container here: the sketch runs inside avvad.ops.McbFusionFn (no PyTorch fallback)")
+        assert x.shape[-1] == self.input_size
+        return ops.CountSketchFn.apply(self.h, self.s, self.output_size, x)
 
 
 class CompactBilinearPooling(nn.Module):
@@ -43,4 +47,7 @@ class CompactBilinearPooling(nn.Module):
         self.force_cpu_scatter_add = force_cpu_scatter_add
 
     def forward(self, x, y=None):
-        raise AvvadError("CompactBilinearPooling is a buffer container here: use DeepVAD_AV(use_mcb=True) (fused HIP path, no fallback)")
+        if y is None:
+            y = x
+        return ops.CompactBilinearPoolingFn.apply(self.sketch1.h, self.sketch1.s, self.sketch2.h, self.sketch2.s,
+                                                  self.output_size, x, y)

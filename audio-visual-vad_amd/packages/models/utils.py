@@ -1,5 +1,6 @@
 """Drop-in for the hot-path members of ``packages/models/utils.py``: ``binary_cross_entropy`` (``:108-113``),
-``f1_loss`` (``:164-203``), ``method3`` (``:36-55``), ``weights_init_normal`` (``:5-26``).  The VAE-era helpers
+``binary_cross_entropy_2classes`` (``:115-116``), ``f1_loss`` (``:164-203``), ``method3`` (``:36-55``),
+``weights_init_normal`` (``:5-26``).  The VAE-era helpers
 of that file are not on the path and are not provided."""
 import torch
 
@@ -24,6 +25,12 @@ def binary_cross_entropy(r, x, eps):
     slice ``r`` (T, y_dim) of logits -- fused HIP loss kernel (value and gradient)."""
     r2 = r.reshape(1, r.shape[0], -1)
     return ops.masked_bce(r2, x.reshape(r2.shape), [r2.shape[1]], eps)
+
+
+def binary_cross_entropy_2classes(r1, r2, x, eps):
+    """-mean(sum(x log(r1+eps) + (1-x) log(r2+eps), dim=-1)) on two probability outputs (reference ``:115-116``,
+    imported by ``scripts/train_video_net.py:18``) -- HIP loss kernel, value and both gradients."""
+    return ops.Bce2ClassesFn.apply(r1, r2, x, eps)
 
 
 def batch_binary_cross_entropy(logits, targets, lengths, eps):

@@ -1,25 +1,29 @@
-"""Entry point mirroring the reference's ``scripts/evaluate_video_net.py`` (module-level constants = config; run from the
-package root: ``python scripts/evaluate_video_net.py``, or under ``torch.distributed.run`` for one process per GPU).
-Synthetic data only (HDF5 / wav readers are out of scope: SURVEY.md 2.1); override sizes with AVVAD_EPOCHS /
-AVVAD_ITEMS / AVVAD_BATCH.  Set WAVENET = True to train on raw waveforms through the WaveNet encoder."""
+"""Evaluation entry point with the settings block of the reference's ``scripts/evaluate_video_net.py``: every
+utterance goes through the classifier, ``sigmoid``, the 0.5 threshold, and ``*_y_hat_soft.pt`` / ``*_y_hat_hard.pt`` are
+written next to each other; utterances are split across ranks (one process per GPU under ``torch.distributed.run``)
+like the reference's ``Pool(4)`` of per-GPU workers (``evaluate_video_net.py`` ``main``).
+Lip-crop sequences come from a synthetic source (the reference reads them from HDF5, evaluate_video_net.py:191-237).
+Run from the package root: ``python scripts/evaluate_video_net.py``; then ``python scripts/run_metrics_dnn_classif.py``."""
 import sys
 sys.path.append('.')
 
-from avvad.train import evaluate_main
+from avvad.train import Stats, evaluate_main
 from packages.models.Video_Net import DeepVAD_video
 
 # Settings (names as in the reference script)
 lstm_layers = 2
 lstm_hidden_size = 1024
 y_dim = 1
-batch_size = 16
-learning_rate = 1e-4
-end_epoch = 1
-classif_dir = None   # path of a checkpoint written by train_video_net.py (or by the reference)
-WAVENET = False
-wavenet_params = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in range(10)] * 2,
-                      en_residual_channel=32, en_dilation_channel=32, en_bottleneck_width=256,
-                      en_pool_kernel_size=16, use_bias=True)
+eps = 1e-8
+std_norm = True
+fs = int(16e3)            # STFT of the audio branch (evaluate_audio_net.py:40-47)
+wlen_sec = 64e-3
+hop_percent = 0.25
+center = False
+pad_at_end = True
+classif_dir = None        # checkpoint written by scripts/train_video_net.py or by the reference (same state_dict keys)
+classif_data_dir = 'eval_out'
+stats_dir = None          # directory holding trainset_video_mean.npy / trainset_video_std.npy
 
 
 def make_model():
@@ -27,4 +31,5 @@ def make_model():
 
 
 if __name__ == '__main__':
-    evaluate_main('video', make_model, checkpoint=classif_dir, waveform=WAVENET and False)
+    stats = Stats.load(stats_dir, eps) if (std_norm and stats_dir) else None
+    evaluate_main('video', make_model, checkpoint=classif_dir, out_dir=classif_data_dir, stats=stats)

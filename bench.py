@@ -5,12 +5,17 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W     # one rank per GPU over RCCL
 
-Workload (BASELINE.json configs[3]/[4], SURVEY.md 8d "C4/C5"; weak scaling): per GPU 64 sequences x T=16 =
-1024 AV frame-pairs: raw 16 kHz waveform (64,1,16*256+2047) -> WaveNet encoder "W0" (20 dilated layers,
+Default workload "c4" (BASELINE.json configs[3]/[4], SURVEY.md 8d "C4/C5"; weak scaling): per GPU 64 sequences x
+T=16 = 1024 AV frame-pairs: raw 16 kHz waveform (64,1,16*256+2047) -> WaveNet encoder "W0" (20 dilated layers,
 R=D=32, Bn=256, P=16), 67x67 gray lip crops (64,16,67,67) -> ResNet-18 trunk, concat -> 2xLSTM(1024) -> FC(1),
 masked summed BCE, backward, bucketed RCCL all-reduce of the flat gradient, fused Adam.  fp32 end to end
-(fp32-input MFMA), synthetic inputs resident in HBM, random-init weights.  At N=8 this is exactly C5
-(8192 global frame-pairs).
+(fp32-input MFMA), synthetic inputs resident in HBM, random-init weights.  At N=8 this is exactly C5's shape
+(8192 global frame-pairs; C5's bf16 arithmetic is `--dtype bf16`, never the headline line).
+
+Other workloads (one JSON line each, same contract):
+  --config c2   audio_net training: wave (256,1,16000) -> W0 (P=60) -> 2xLSTM(1024) -> FC; 15 360 frames / step
+  --config c3   video_net training: 512 lip crops as (32,16,67,67) -> ResNet-18 -> 2xLSTM(1024) -> FC; 512 frames / step
+  --forward-only        time the inference forward (eval mode, no autograd tape) instead of the training step
 
 One "step" = forward + loss + backward + gradient exchange + Adam + zero_grad.  Rank 0 prints ONE JSON line.
 """
@@ -26,24 +31,51 @@ for p in (ROOT, os.path.join(ROOT, "audio-visual-vad_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-N_SEQ, T_FRAMES, HOP, H_IMG = 64, 16, 256, 67
-W0 = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in range(10)] * 2, en_residual_channel=32,
-          en_dilation_channel=32, en_bottleneck_width=256, en_pool_kernel_size=T_FRAMES, use_bias=True)
+HOP, H_IMG = 256, 67
 RF = 2048
+
+
+def w0(pool):
+    return dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in range(10)] * 2, en_residual_channel=32,
+                en_dilation_channel=32, en_bottleneck_width=256, en_pool_kernel_size=pool, use_bias=True)
+
+
+N_SEQ, T_FRAMES = 64, 16
+W0 = w0(T_FRAMES)
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
-# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of `bench.py --no-extras`, dominant kernel, per
-# launch: FETCH_SIZE 99,916 KB x 2 (gfx950 counts 128-B requests at 64 B) + WRITE_SIZE 56,047 KB
-# (tools/pmc_summary.py -> profiles/r01_pmc_{fetch,write}_size_per_kernel.csv)
-TRAFFIC_PER_LAUNCH_BYTES = int((2 * 99916 + 56047) * 1024)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
+PEAK_HBM_GBS = 8000.0     # HBM3E spec (6.29 TB/s measured copy)
+# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_summary.py -> profiles/r02_pmc_*_per_kernel.csv);
+# FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> doubled.  Bytes per launch of the two roofline kernels.
+TRAFFIC = {"conv_fwd": None, "wn_layer": None}
+try:
+    with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as _f:
+        TRAFFIC.update(json.load(_f))
+except OSError:
+    pass
+
+CONFIGS = {
+    # name: (kind, sequences per GPU, frames per sequence, samples per sequence, frames counted per step)
+    "c4": dict(kind="av", n_seq=64, T=16, L=16 * HOP + RF - 1,
+               what="AV_net fused training step (WaveNet-W0 encoder + ResNet-18 trunk + concat + 2xLSTM1024 + FC, masked BCE, "
+                    "backward, RCCL all-reduce, fused Adam): BASELINE configs[3]/[4] per-GPU shard"),
+    "c2": dict(kind="audio", n_seq=256, T=60, L=16000,
+               what="audio_net training step (WaveNet-W0 encoder on 256 one-second 16 kHz chunks + 2xLSTM1024 + FC, masked BCE, "
+                    "backward, fused Adam): BASELINE configs[1]"),
+    "c3": dict(kind="video", n_seq=32, T=16, L=0,
+               what="video_net training step (ResNet-18 trunk on 512 67x67 lip crops + 2xLSTM1024 + FC, masked BCE, backward, "
+                    "fused Adam): BASELINE configs[2]"),
+}
 
 
-def make_inputs(torch, n_seq, seed, device):
+def make_inputs(torch, n_seq, seed, device, T=T_FRAMES, L=None, kind="av"):
     g = torch.Generator().manual_seed(seed)
-    wave = torch.rand(n_seq, 1, T_FRAMES * HOP + RF - 1, generator=g) * 2 - 1
+    L = T * HOP + RF - 1 if L is None else L
+    wave = torch.rand(n_seq, 1, max(L, 1), generator=g) * 2 - 1
     wave = wave / wave.abs().amax(dim=2, keepdim=True)            # peak-normalised like data_handling.py:441
-    video = torch.randn(n_seq, T_FRAMES, H_IMG, H_IMG, generator=g)
-    target = (torch.rand(n_seq, T_FRAMES, 1, generator=g) > 0.5).float()
-    lengths = torch.full((n_seq,), T_FRAMES, dtype=torch.long)
+    video = torch.randn(n_seq, T, H_IMG, H_IMG, generator=g) if kind != "audio" else torch.zeros(1)
+    target = (torch.rand(n_seq, T, 1, generator=g) > 0.5).float()
+    lengths = torch.full((n_seq,), T, dtype=torch.long)
     return [t.to(device) if device else t for t in (wave, video, target, lengths)]
 
 
@@ -62,13 +94,74 @@ def trunk_conv_shapes(n):
     return out
 
 
+# ---------------------------------------------------------------------------------------------- algorithmic work
+def encoder_work(n_seq, L, cfg):
+    """forward FLOPs and layer-at-a-time activation bytes (one read + one write of every layer's input/output plane)
+    of the W0 encoder on n_seq sequences of L samples."""
+    R, D, fw, Bn = cfg["en_residual_channel"], cfg["en_dilation_channel"], cfg["filter_width"], cfg["en_bottleneck_width"]
+    Li = L - (fw - 1)
+    flops = 2.0 * n_seq * Li * R * cfg["quantization_channel"] * fw
+    byts = 4.0 * n_seq * (L + R * Li)
+    for d in cfg["dilations"]:
+        Lo = Li - d * (fw - 1)
+        flops += 2.0 * n_seq * Lo * (D * R * fw + R * D)
+        byts += 4.0 * n_seq * R * (Li + Lo)
+        Li = Lo
+    flops += 2.0 * n_seq * Li * Bn * R
+    byts += 4.0 * n_seq * (R * Li + Bn * cfg["en_pool_kernel_size"])
+    return flops, byts
+
+
+def trunk_work(n):
+    """forward FLOPs (3 identical input channels folded: conv1 reads 1 channel) and layer-at-a-time bytes per SURVEY 8d
+    (2.5 MB / frame: every activation written once and read once, residual re-reads)."""
+    flops = 2.0 * n * 34 * 34 * 64 * 49
+    for (c, co, h, w, ks, st, pad) in trunk_conv_shapes(n):
+        ho = (h + 2 * pad - ks) // st + 1
+        flops += 2.0 * n * ho * ho * co * ks * ks * c
+    return flops, 2.5e6 * n
+
+
+def head_work(n_seq, T, in_dim, H=1024):
+    flops = 2.0 * n_seq * T * (4 * H * (in_dim + H) + 4 * H * 2 * H + H)
+    byts = 4.0 * (4 * H * (in_dim + H) + 4 * H * 2 * H) * (1 + T) + 4.0 * n_seq * T * (in_dim + 10 * H)   # W_hh re-streamed per step
+    return flops, byts
+
+
+def step_work(cfg_name, forward_only):
+    c = CONFIGS[cfg_name]
+    fl = by = 0.0
+    in_dim = 0
+    if c["kind"] in ("av", "audio"):
+        f, b = encoder_work(c["n_seq"], c["L"], w0(c["T"]))
+        fl, by, in_dim = fl + f, by + b, in_dim + 256
+    if c["kind"] in ("av", "video"):
+        f, b = trunk_work(c["n_seq"] * c["T"])
+        fl, by, in_dim = fl + f, by + b, in_dim + 512
+    f, b = head_work(c["n_seq"], c["T"], in_dim)
+    fl, by = fl + f, by + b
+    k = 1.0 if forward_only else 3.0       # backward = data + weight gradients: 2x the forward products (SURVEY 8d)
+    return fl * k, by * k
+
+
+# ---------------------------------------------------------------------------------------------- roofline probes
+def _events(torch, fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps      # ms
+
+
 def roofline_probe(torch, n_frames, reps=5):
-    """Per-launch duration (HIP events on the launch stream) of the dominant kernel: the fp32-MFMA
-    implicit-GEMM convolution igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,EpiStore>, i.e. the forward
-    of every trunk conv with Cout >= 128 (15 launches per step).  achieved = algorithmic FLOPs of those
-    launches (2*N*Ho*Wo*Co*KS^2*C each) / their summed duration.  `traffic` is NOT measured here: it is the
-    per-launch HBM-side byte count from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE in separate runs; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-B/lane reads)."""
+    """Per-launch duration (HIP events on the launch stream = torch's current stream) of the dominant kernel: the
+    fp32-MFMA implicit-GEMM convolution igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,...>, i.e. the forward of
+    every trunk conv with Cout >= 128 (15 launches per step).  achieved = algorithmic FLOPs of those launches
+    (2*N*Ho*Wo*Co*KS^2*C each) / their summed duration, everything the launch needs included.  `traffic` is the
+    per-launch HBM-side byte count from the rocprofv3 PMC passes committed under profiles/."""
     from avvad import _lib as L
     lib = L.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -82,19 +175,8 @@ def roofline_probe(torch, n_frames, reps=5):
         wf = torch.randn(ks * ks * c, co, device="cuda") * 0.05
         y = torch.empty(n_frames, ho, ho, co, device="cuda")
         d = L.ConvDesc(n_frames, h, w, c, co, ks, stride, pad)
-        for _ in range(2):
-            L.check(lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), st), "conv fwd")
-        # time the GEMM kernel alone: the stream-K zero-fill of the output is a separate 13 us kernel with its own
-        # line in the rocprof summary (zero_strided); with it skipped the events bracket only igemm::kernel launches
-        os.environ["AVVAD_SKIP_ZERO"] = "1"
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), st)
-        e1.record()
-        torch.cuda.synchronize()
-        del os.environ["AVVAD_SKIP_ZERO"]
-        ms = e0.elapsed_time(e1) / reps
+        L.check(lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), st), "conv fwd")
+        ms = _events(torch, lambda: lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), st), reps)
         flop = 2.0 * n_frames * ho * ho * co * ks * ks * c
         per.append((c, co, h, ks, stride, ms, flop / ms / 1e9))
         tot_flop += flop
@@ -104,9 +186,43 @@ def roofline_probe(torch, n_frames, reps=5):
     return {"bound": "mfma", "kernel": "igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,EpiStore> (trunk conv forward, Cout>=128)",
             "launches_per_step": n_launch, "avg_launch_us": round(1e3 * tot_ms / n_launch, 2),
             "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-            "traffic": TRAFFIC_PER_LAUNCH_BYTES, "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC, profiles/r01_pmc_*_size_per_kernel.csv)",
+            "traffic": TRAFFIC.get("conv_fwd"),
+            "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC, profiles/r02_pmc_*_per_kernel.csv)",
             "per_shape": [{"C": a, "Co": b, "HW": c_, "k": d_, "s": e, "us": round(1e3 * f, 1), "TFLOPs": round(g, 1)}
                           for (a, b, c_, d_, e, f, g) in per]}
+
+
+def roofline_probe_hbm(torch, n_seq, L, reps=10):
+    """The dominant HBM-bound kernel: one layer-at-a-time residual block of the encoder (wn_block_fwd_mfma: R = D = 32,
+    filter width 2, the large-dilation layers that cannot be fused in LDS), timed per launch with HIP events through the
+    single-layer entry point avvad_wavenet_block_fwd.  Algorithmic bytes per launch = one read of s_in + one write of
+    s_out (the second tap and the residual are re-reads of the same plane: L2 hits by design) = 256 B per output sample."""
+    from avvad import _lib as L_
+    lib = L_.lib()
+    if not hasattr(lib, "avvad_wavenet_block_fwd"):
+        return None
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = []
+    for dil in (64, 512):
+        Lin = L - 1 - 63                       # the plane a d=64 layer of the first stack sees (after causal + d=1..32)
+        Lo = Lin - dil
+        s_in = torch.randn(n_seq, 32, Lin, device="cuda")
+        s_out = torch.empty(n_seq, 32, Lo, device="cuda")
+        wd, bd = torch.randn(32, 32, 2, device="cuda") * 0.1, torch.randn(32, device="cuda") * 0.1
+        we, be = torch.randn(32, 32, 1, device="cuda") * 0.1, torch.randn(32, device="cuda") * 0.1
+        call = lambda: lib.avvad_wavenet_block_fwd(L_.ptr(s_in), L_.ptr(wd), L_.ptr(bd), L_.ptr(we), L_.ptr(be), L_.ptr(s_out),
+                                                   n_seq, Lin, dil, st)
+        L_.check(call(), "avvad_wavenet_block_fwd")
+        ms = _events(torch, call, reps)
+        byts = 4.0 * n_seq * 32 * (Lin + Lo)
+        out.append((dil, ms, byts))
+    ms = sum(m for _, m, _ in out) / len(out)
+    byts = sum(b for _, _, b in out) / len(out)
+    ach = byts / ms / 1e6
+    return {"bound": "hbm", "kernel": "wn_block_fwd_mfma (encoder residual block, layer-at-a-time, R=D=32 fw=2)",
+            "avg_launch_us": round(1e3 * ms, 2), "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(byts), "traffic": TRAFFIC.get("wn_layer"),
+            "per_dilation": [{"d": d, "us": round(1e3 * m, 1), "GBs": round(b / m / 1e6, 1)} for d, m, b in out]}
 
 
 def cpu_baseline(torch, n_seq=32):
@@ -137,19 +253,19 @@ def cpu_baseline(torch, n_seq=32):
                       "median of 10 after 1 warm-up, %.2f s each" % (n_seq, T_FRAMES, t)}
 
 
-def parity_probe(torch):
-    """CPU-reference max|delta| of the logits on a small ragged AV batch (the second half of the metric)."""
+def parity_probe(torch, model):
+    """CPU-reference max|delta| on a RAGGED slice of the benched model itself: the benchmark's own weights
+    (WaveNet W0, ResNet-18, 2xLSTM(1024), FC), 4 sequences of the benchmark's shape with lengths 16/9/12/5, train-mode
+    BatchNorm, logits vs the oracle on the host."""
     from oracle import models
-    from packages.models.AV_Net import DeepVAD_AV
-    cfg = dict(W0, en_pool_kernel_size=4)
-    torch.manual_seed(1)
-    m = DeepVAD_AV(2, 64, 1, wavenet_params=cfg)
-    wave = torch.randn(3, 1, 4 * HOP + RF - 1) * 0.3
-    video = torch.randn(3, 4, H_IMG, H_IMG)
-    lens = [4, 2, 3]
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    ref = models.av_net(sd, wave, video, lens, 2, training=True, wavenet_cfg=cfg)
-    y = m.to("cuda").train()(wave.cuda(), video.cuda(), lens)
+    wave, video, target, lengths = make_inputs(torch, 4, 4321, None)
+    lens = [16, 9, 12, 5]
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    ref = models.av_net(sd, wave, video, lens, 2, training=model.training, wavenet_cfg=W0)
+    rs = {k: model.state_dict()[k].clone() for k in sd if "running" in k or "num_batches" in k}
+    with torch.no_grad():
+        y = model(wave.cuda(), video.cuda(), torch.LongTensor(lens))
+    model.load_state_dict(rs, strict=False)                      # the probe must not move the running statistics
     return float((y.detach().cpu() - ref).abs().max())
 
 
@@ -158,14 +274,21 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
+    ap.add_argument("--forward-only", action="store_true", help="inference forward instead of the training step")
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: BASELINE configs[4] arithmetic (own line, never the headline)")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="CUs left free by the persistent conv grids (room for RCCL kernels at N>1)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / parity probes")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
+    from avvad import _lib as L
     from avvad import dist as avd
     from avvad.optim import FlatAdam
     from packages.models.AV_Net import DeepVAD_AV
+    from packages.models.Audio_Net import DeepVAD_audio
+    from packages.models.Video_Net import DeepVAD_video
     from packages.models.utils import batch_binary_cross_entropy
 
     rank, world, local = avd.init_from_env("nccl")
@@ -174,21 +297,50 @@ def main():
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if args.reserve_cus:
+        L.set_option("max_cus", 256 - args.reserve_cus)
+    if args.dtype == "bf16":
+        if L.lib().avvad_set_option(b"bf16", 1) != 0:
+            raise SystemExit("this build of libavvad_hip.so has no bf16 path")
 
+    cfg = CONFIGS[args.config]
+    kind, n_seq, T = cfg["kind"], cfg["n_seq"], cfg["T"]
     torch.manual_seed(0)                       # identical initial weights on every rank
-    model = DeepVAD_AV(2, 1024, 1, use_mcb=False, eps=1e-8, wavenet_params=W0).to(dev).train()
-    wave, video, target, lengths = make_inputs(torch, N_SEQ, 1234 + rank, dev)
-    opt = FlatAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999))
-    reducer = avd.BucketReducer(opt.params, opt.flat_grad, opt.offsets)
+    if kind == "av":
+        model = DeepVAD_AV(2, 1024, 1, use_mcb=False, eps=1e-8, wavenet_params=w0(T))
+    elif kind == "audio":
+        model = DeepVAD_audio(2, 1024, 1, wavenet_params=w0(T))
+    else:
+        model = DeepVAD_video(2, 1024, 1)
+    model = model.to(dev).train(not args.forward_only)
+    wave, video, target, lengths = make_inputs(torch, n_seq, 1234 + rank, dev, T=T, L=cfg["L"], kind=kind)
 
-    def step():
-        y = model(wave, video, lengths)
-        loss = batch_binary_cross_entropy(y, target, lengths, 1e-8)
-        loss.backward()
-        reducer.finish()
-        opt.step()
-        opt.zero_grad()
-        return loss
+    def fwd():
+        if kind == "av":
+            return model(wave, video, lengths)
+        if kind == "audio":
+            return model(wave, lengths)
+        return model(video, lengths)
+
+    if args.forward_only:
+        for p_ in model.parameters():
+            p_.requires_grad = False
+
+        def step():
+            with torch.no_grad():
+                return fwd().sum()
+    else:
+        opt = FlatAdam(model.parameters(), lr=1e-4, betas=(0.9, 0.999))
+        reducer = avd.BucketReducer(opt.params, opt.flat_grad, opt.offsets,
+                                    names=[n for n, q in model.named_parameters() if q.requires_grad])
+
+        def step():
+            loss = batch_binary_cross_entropy(fwd(), target, lengths, 1e-8)
+            loss.backward()
+            reducer.finish()
+            opt.step()
+            opt.zero_grad()
+            return loss
 
     def log(msg):
         if rank == 0:
@@ -217,21 +369,33 @@ def main():
     log("timed region: %.3f s for %d steps" % (dt, args.steps))
 
     if rank == 0:
-        fp_per_step = world * N_SEQ * T_FRAMES
-        out = {"metric": "AV frame-pairs/sec (fwd+bwd)", "value": round(fp_per_step * args.steps / dt, 1),
-               "unit": "frame-pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "AV_net fused training step (WaveNet-W0 encoder + ResNet-18 trunk + concat + 2xLSTM1024 + FC, "
-                                      "masked BCE, backward, RCCL all-reduce, fused Adam): BASELINE configs[3]/[4] per-GPU shard",
-                          "per_gpu_frame_pairs": N_SEQ * T_FRAMES, "global_frame_pairs": fp_per_step, "sequences_per_gpu": N_SEQ,
-                          "frames_per_sequence": T_FRAMES, "samples_per_sequence": T_FRAMES * HOP + RF - 1,
-                          "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4)}}
+        fp_per_step = world * n_seq * T
+        flops, byts = step_work(args.config, args.forward_only)
+        t_step = dt / args.steps
+        peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else PEAK_F32_TFLOPS
+        unit = {"av": "frame-pairs/s", "audio": "frames/s", "video": "frames/s"}[kind]
+        mode = "fwd" if args.forward_only else "fwd+bwd"
+        out = {"metric": "AV frame-pairs/sec (%s)" % mode if kind == "av" else "%s_net frames/sec (%s)" % (kind, mode),
+               "value": round(fp_per_step * args.steps / dt, 1),
+               "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(1e3 * t_step, 3), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": cfg["what"] if not args.forward_only else cfg["what"].replace("training step", "inference forward"),
+                          "name": args.config, "per_gpu_frame_pairs": n_seq * T, "global_frame_pairs": fp_per_step,
+                          "sequences_per_gpu": n_seq, "frames_per_sequence": T, "samples_per_sequence": cfg["L"],
+                          "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
+                          # whole-step fractions of SURVEY 8d (per GPU): algorithmic FLOPs / layer-at-a-time bytes over the step time
+                          "flop_frac": round(flops / t_step / 1e12 / peak, 4), "hbm_frac": round(byts / t_step / 1e9 / PEAK_HBM_GBS, 4),
+                          "algorithmic_tflop_per_step": round(flops / 1e12, 4), "layerwise_gb_per_step": round(byts / 1e9, 3)}}
         if not args.no_extras:
-            out["roofline"] = roofline_probe(torch, N_SEQ * T_FRAMES)
-            log("roofline probe done")
-            if world == 1:     # CPU baseline and CPU-reference delta: rank 0 at N=1 only
-                out["cpu_ref_max_abs_delta"] = parity_probe(torch)
+            if kind != "audio":
+                out["roofline"] = roofline_probe(torch, n_seq * T)
+            hb = roofline_probe_hbm(torch, n_seq if kind != "video" else 64, cfg["L"] or (16 * HOP + RF - 1))
+            if hb is not None:
+                out["roofline_hbm" if "roofline" in out else "roofline"] = hb
+            log("roofline probes done")
+            if world == 1 and kind == "av" and args.dtype == "f32":     # CPU baseline and CPU-reference delta: rank 0 at N=1 only
+                out["cpu_ref_max_abs_delta"] = parity_probe(torch, model)
                 log("parity probe done")
                 out["cpu_baseline"] = cpu_baseline(torch)
                 log("cpu baseline done")

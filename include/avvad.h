@@ -13,8 +13,10 @@
  *   - the caller allocates every buffer, including the workspace
  *     (size from the matching *_workspace() query, bytes);
  *   - asynchronous on the given hipStream_t, never synchronises, never
- *     allocates; no hidden state -> re-entrant across streams and devices,
- *     capturable into a hipGraph;
+ *     allocates, keeps no per-call state -> re-entrant across streams and
+ *     devices, capturable into a hipGraph.  The only process-wide state is the
+ *     table of schedule options below (avvad_set_option): it is filled ONCE
+ *     from the AVVAD_* environment variables on first use and never re-read;
  *   - returns AVVAD_OK or a negative AVVAD_E* code, never throws;
  *   - fp32 storage and fp32 arithmetic (fp32-input MFMA == ordered fmaf chain).
  */
@@ -38,6 +40,14 @@ typedef void* avvad_stream_t; /* hipStream_t */
 /* library / build identification ("gfx950", ABI version) */
 const char* avvad_version(void);
 int avvad_abi_version(void);
+
+/* Schedule options (tuning / debugging; production leaves them alone).  Names: "no_streamk" (1 = whole-tile,
+ * bit-reproducible GEMM schedule), "igemm_variant", "kmajor", "lstm_no_fused_step", "lstm_no_persistent",
+ * "no_stem_kernel", "no_tall", "wn_no_fused_tail", "wn_no_fused_wgrad", "wn_no_group", "max_cus" (cap on the CUs
+ * a persistent grid occupies, so that RCCL's kernels find free CUs during data-parallel training).  Initial values
+ * come from AVVAD_<NAME> in the environment, read once.  Returns AVVAD_EINVAL for an unknown name. */
+int avvad_set_option(const char* name, int value);
+int avvad_get_option(const char* name);
 
 /* ------------------------------------------------------------------------
  * Dense GEMM on fp32 MFMA:  C[M,N] (+)= op(A) . op(B) (+ bias[N])
@@ -79,7 +89,7 @@ typedef struct {
   int n_layers;
   const int* dilations_h; /* host array [n_layers]                     */
   int use_bias;
-  int save_for_backward; /* forward keeps s_i and z_i in the workspace */
+  int save_for_backward; /* forward keeps every s_i in the workspace (z_i is rebuilt by the backward) */
 } avvad_wavenet_desc;
 
 /* parameter pointers, host arrays of device pointers */
@@ -114,6 +124,14 @@ int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* p, float* o
 int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* p, const float* dout,
                       const avvad_wavenet_grads* g, float* dwave, const avvad_wavenet_desc* d,
                       void* ws, size_t ws_bytes, avvad_stream_t s);
+
+/* One residual block of the R = D = 32, filter_width 2 encoder on its own (wavenet_autoencoder.py:80-86):
+ *   s_out[b][r][t] = b_dense[r] + sum_d W_dense[r][d] relu(b_dil[d] + sum_{c,k} W_dil[d][c][k] relu(s_in[b][c][t + k*dil]))
+ *                    + s_in[b][r][t + dil]          s_in [B][32][Lin] -> s_out [B][32][Lin - dil]
+ * The layer-at-a-time kernel of the large dilations; bench.py times it per launch for its HBM roofline entry.
+ * Biases may be NULL. */
+int avvad_wavenet_block_fwd(const float* s_in, const float* w_dil, const float* b_dil, const float* w_dense,
+                            const float* b_dense, float* s_out, int B, int Lin, int dil, avvad_stream_t s);
 
 /* ------------------------------------------------------------------------
  * ResNet-18 trunk over gray lip crops
@@ -225,6 +243,23 @@ int avvad_mcb_fusion_bwd(const float* audio, const float* video, const int64_t* 
                          float* daudio, float* dvideo, float* dbn_w, float* dbn_b,
                          const avvad_mcb_desc* d, void* ws, size_t ws_bytes, avvad_stream_t s);
 
+/* The bare modules of packages/models/compact_bilinear_pooling.py, for callers that use them outside DeepVAD_AV:
+ *   CountSketch.forward (:59-114 -> CountSketchFn_forward :7-27):  out[row][h[i]] += s[i] * x[row][i]
+ *   CountSketchFn_backward (:30-38):                               dx[row][i] = s[i] * dout[row][h[i]]
+ *   CompactBilinearPooling.forward (:222-263 -> CompactBilinearPoolingFn.forward :140-173): the raw vector
+ *     y = irfft(rfft(psi(a,h1,s1)) * rfft(psi(v,h2,s2))) = circular convolution of the two sketches, [rows][D]
+ *   CompactBilinearPoolingFn.backward (:175-220): da, dv (either may be NULL; overwritten).
+ * D <= 2048. */
+int avvad_count_sketch_fwd(const float* x, const int64_t* h, const float* s, float* out, int rows, int In, int D,
+                           avvad_stream_t st);
+int avvad_count_sketch_bwd(const float* dout, const int64_t* h, const float* s, float* dx, int rows, int In, int D,
+                           avvad_stream_t st);
+int avvad_mcb_fwd(const float* a, const float* v, const int64_t* h1, const float* s1, const int64_t* h2,
+                  const float* s2, float* y, int rows, int A, int V, int D, avvad_stream_t st);
+int avvad_mcb_bwd(const float* a, const float* v, const int64_t* h1, const float* s1, const int64_t* h2,
+                  const float* s2, const float* dy, float* da, float* dv, int rows, int A, int V, int D,
+                  avvad_stream_t st);
+
 /* ------------------------------------------------------------------------
  * STFT log-power front-end: framing + periodic Hann + real DFT (one MFMA GEMM) + |X|^2 (+ log)
  * Replaces: stft_pytorch packages/processing/stft.py:102-151 (center=False; the optional one-hop zero pad at
@@ -243,6 +278,19 @@ size_t avvad_stft_workspace(const avvad_stft_desc* d);
 int avvad_stft(const float* wave, float* out, const avvad_stft_desc* d, int mode, void* ws, size_t ws_bytes,
                avvad_stream_t s);
 
+/* The evaluate scripts' feature chain in one call (scripts/evaluate_audio_net.py:131-163): STFT -> |X|^2 ->
+ * log(. + d->eps) -> (x - mean[f]) / (std[f] + norm_eps), the standardisation folded into the DFT's epilogue pass.
+ * mean / std: [F] train-set statistics.  out [B][T][F]. */
+int avvad_stft_features(const float* wave, const float* mean, const float* std_, float* out,
+                        const avvad_stft_desc* d, float norm_eps, void* ws, size_t ws_bytes, avvad_stream_t s);
+/* out[b][:] = x[b][:] / max|x[b][:]|   (peak normalisation, scripts/evaluate_audio_net.py:125-127); out may alias x */
+int avvad_peak_normalize(const float* x, float* out, int B, long L, avvad_stream_t s);
+/* out[r][f] = (x[r][f] - mean[f]) / (std[f] + eps)  -- input standardisation of the train / evaluate loops
+ * (scripts/train_AV_net.py:286-291, evaluate_audio_net.py:158-163).  nstat == F: per-bin statistics (audio,
+ * 513 x 1 in the reference); nstat == 1: one scalar pair (video, 1 x 1).  out may alias x. */
+int avvad_standardize(const float* x, const float* mean, const float* std_, float* out, size_t rows, int F,
+                      int nstat, float eps, avvad_stream_t s);
+
 /* ------------------------------------------------------------------------
  * Masked BCE-with-eps loss, summed over sequences
  * Replaces: binary_cross_entropy packages/models/utils.py:108-113 and its caller
@@ -253,6 +301,13 @@ int avvad_stft(const float* wave, float* out, const avvad_stft_desc* d, int mode
  * ---------------------------------------------------------------------- */
 int avvad_bce_masked(const float* logits, const float* targets, const int* lengths, float* loss,
                      float* dlogits, int B, int T, int Y, float eps, avvad_stream_t s);
+
+/* Two-output-unit BCE on probabilities: binary_cross_entropy_2classes packages/models/utils.py:115-116
+ * (imported by scripts/train_video_net.py:18):
+ *   loss = -mean_rows( sum_y [ x log(r1 + eps) + (1 - x) log(r2 + eps) ] ).
+ * r1, r2, x [rows][Y]; loss one float; dr1 / dr2 (d loss / d r, may be NULL) [rows][Y]. */
+int avvad_bce_2classes(const float* r1, const float* r2, const float* x, float* loss, float* dr1, float* dr2,
+                       long rows, int Y, float eps, avvad_stream_t s);
 
 /* ------------------------------------------------------------------------
  * Fused Adam step over a flat parameter buffer

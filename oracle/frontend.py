@@ -49,6 +49,27 @@ def log_power(S, eps=1e-8):
     return torch.log(S[..., 0] ** 2 + S[..., 1] ** 2 + eps)
 
 
+def audio_features(x_t, mean=None, std=None, n_label_frames=None, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, eps=1e-8):
+    """``process_utt`` up to the classifier input, ``scripts/evaluate_audio_net.py:122-163``:
+    x / max|x| -> stft_pytorch(center=False, pad_at_end=True) -> re^2 + im^2 -> crop to the label's frame count ->
+    log(. + eps) -> transpose to (frames, bins) -> ``x -= mean.T; x /= (std + eps).T`` -> [None].
+    x_t (L,) -> (1, T, 513); mean / std are the (513, 1) train-set statistics (or None: ``std_norm`` off)."""
+    x_t = x_t / torch.max(torch.abs(x_t))
+    x_tf = stft(x_t, fs=fs, wlen_sec=wlen_sec, hop_percent=hop_percent, center=False, pad_at_end=True)
+    x = x_tf[..., 0] ** 2 + x_tf[..., 1] ** 2
+    if n_label_frames is not None and n_label_frames < x.shape[-1]:
+        x = x[..., :n_label_frames]
+    x = torch.log(x + eps).T
+    if mean is not None:
+        x = (x - mean.reshape(-1, 1).T) / (std.reshape(-1, 1) + eps).T
+    return x[None]
+
+
+def standardize(x, mean, std, eps=1e-8):
+    """``x_norm = x - mean.T; x_norm /= (std + eps).T`` (``scripts/train_AV_net.py:286-291``): mean/std (F,1) or (1,1)."""
+    return (x - mean.reshape(-1, 1).T) / (std.reshape(-1, 1) + eps).T
+
+
 def pad_time_first(samples, max_len):
     """samples: list of (..., T_i) -> (B, T, ...) zero padded (``utils.py:51-72``)."""
     out = torch.zeros((len(samples),) + tuple(samples[0].shape[:-1]) + (max_len,))

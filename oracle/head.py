@@ -64,6 +64,11 @@ def bce_with_eps(r, x, eps):
     return -torch.mean(x * torch.log(s + eps) + (1 - x) * torch.log(1 - s + eps))
 
 
+def bce_2classes(r1, r2, x, eps):
+    """``binary_cross_entropy_2classes`` (``models/utils.py:115-116``): r1, r2 probabilities."""
+    return -torch.mean(torch.sum(x * torch.log(r1 + eps) + (1 - x) * torch.log(r2 + eps), dim=-1))
+
+
 def batch_loss(logits, targets, lengths, eps):
     """Caller loop ``scripts/train_AV_net.py:298-301``: per-sequence mean over the
     valid frames (and y_dim), SUMMED over the batch (the /B is commented out, ``:302``)."""

@@ -27,6 +27,22 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
+@pytest.fixture
+def lib_options():
+    """Set schedule options of libavvad_hip.so for one test (avvad_set_option) and restore them afterwards.  The
+    library reads AVVAD_* from the environment only once, so in-process switches go through this."""
+    from avvad import _lib as L
+    saved = {}
+
+    def set_option(name, value):
+        if name not in saved:
+            saved[name] = L.get_option(name)
+        L.set_option(name, value)
+    yield set_option
+    for k, v in saved.items():
+        L.set_option(k, v)
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
     return {k: z[k] for k in z.files}

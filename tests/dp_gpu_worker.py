@@ -26,8 +26,8 @@ def main():
     model = case.make_model().to(dev).eval()            # eval: BatchNorm uses running statistics, so shards are independent
     wave, video, target, lengths = [t.to(dev) for t in case.make_batch()]
     opt = FlatAdam(model.parameters(), lr=1e-3)
-    red = avd.BucketReducer(opt.params, opt.flat_grad, opt.offsets, bucket_bytes=1 << 20)   # several buckets
-    red._names = {id(p_): n_ for n_, p_ in model.named_parameters()}
+    red = avd.BucketReducer(opt.params, opt.flat_grad, opt.offsets, bucket_bytes=1 << 20,   # several buckets, cut at sub-modules
+                            names=[n_ for n_, p_ in model.named_parameters() if p_.requires_grad], min_group_bytes=1 << 12)
     lengths_s, wave_s, video_s, target_s = avd.shard_batch([lengths, wave, video, target], rank, world)
     for step in range(2):                                # two steps: the reducer's per-step bookkeeping is reset in between
         y = model(wave_s, video_s, lengths_s)

@@ -83,6 +83,67 @@ def test_dropin_state_dict_keys_and_sizes():
     m.load_state_dict(sd)
 
 
+def test_names_the_reference_scripts_import():
+    """Exactly the ``from packages...`` imports of the six hot-path scripts of the reference must resolve against
+    the drop-in package (scripts/train_AV_net.py:16-20, train_audio_net.py:18-21, train_video_net.py:17-19,
+    evaluate_{AV,audio,video}_net.py:14-16).  ``packages.data_handling`` / ``packages.visualization`` (HDF5 readers,
+    matplotlib figures) are out of scope and not listed."""
+    import importlib
+    wanted = {
+        "packages.models.AV_Net": ["DeepVAD_AV"],
+        "packages.models.Video_Net": ["DeepVAD_video"],
+        "packages.models.Audio_Net": ["DeepVAD_audio"],
+        "packages.models.utils": ["binary_cross_entropy", "binary_cross_entropy_2classes", "f1_loss"],
+        "packages.utils": ["count_parameters", "collate_many2many_AV", "collate_many2many_AV_waveform",
+                           "collate_many2many_audio", "collate_many2many_audio_waveform", "my_collate",
+                           "collate_many2many_video"],
+        "packages.processing.stft": ["stft_pytorch"],
+        "packages.models.compact_bilinear_pooling": ["CountSketch", "CompactBilinearPooling"],
+        "packages.models.wavenet_autoencoder": ["wavenet_autoencoder"],
+    }
+    for mod, names in wanted.items():
+        m = importlib.import_module(mod)
+        assert m.__file__.startswith(os.path.join(ROOT, "audio-visual-vad_amd")), m.__file__
+        for n in names:
+            assert callable(getattr(m, n)), (mod, n)
+    # the settings blocks of the entry points parse and name the reference's knobs
+    import ast
+    for f in ("train_AV_net", "train_audio_net", "train_video_net", "evaluate_AV_net", "evaluate_audio_net", "evaluate_video_net"):
+        tree = ast.parse(open(os.path.join(ROOT, "audio-visual-vad_amd", "scripts", f + ".py")).read())
+        names = {t.id for n in ast.walk(tree) if isinstance(n, ast.Assign) for t in n.targets if isinstance(t, ast.Name)}
+        assert {"lstm_layers", "lstm_hidden_size", "y_dim", "eps", "std_norm"} <= names, (f, names)
+
+
+def test_schedule_options_are_a_table_not_the_environment(monkeypatch):
+    """The library reads AVVAD_* once (first use); later changes go through avvad_set_option only."""
+    from avvad import _lib as L
+    base = L.get_option("no_streamk")
+    monkeypatch.setenv("AVVAD_NO_STREAMK", "all" if base != 1 else "0")
+    assert L.get_option("no_streamk") == base                 # the environment is not consulted again
+    L.set_option("no_streamk", 1)
+    assert L.get_option("no_streamk") == 1
+    L.set_option("no_streamk", base)
+    with pytest.raises(L.AvvadError):
+        L.set_option("no_such_option", 1)
+
+
+def test_standardisation_stats_and_waveform_loader(tmp_path):
+    from avvad.train import Stats, load_waveform
+    from conftest import GOLDEN
+    np.save(tmp_path / "trainset_audio_mean.npy", np.zeros((513, 1), np.float32))
+    np.save(tmp_path / "trainset_audio_std.npy", np.ones((513, 1), np.float32))
+    st = Stats.load(str(tmp_path))
+    assert st.get("audio_mean", "cpu").shape == (513,) and st.get("video_mean", "cpu") is None
+    x = torch.zeros(2, 3, 67, 67)
+    assert st.video(x) is x                                    # no video statistics -> untouched
+    w, fs = load_waveform(os.path.join(GOLDEN, "utt_sa1.npz"))
+    assert fs == 16000 and w.shape == (48100,)
+    from scipy.io import wavfile
+    wavfile.write(str(tmp_path / "a.wav"), 16000, (w.numpy() * 32768).astype(np.int16))
+    w2, _ = load_waveform(str(tmp_path / "a.wav"))
+    np.testing.assert_array_equal(w.numpy(), w2.numpy())
+
+
 def test_no_cpu_fallback():
     from avvad import AvvadError
     from packages.models.Audio_Net import DeepVAD_audio
@@ -247,3 +308,39 @@ def test_bucket_reducer_counts_each_parameter_once_per_step():
     assert red.pending == [0] and not red._seen
     red._on_grad(ps[0])
     assert red.pending[0] == 1
+
+
+def test_bucket_reducer_groups_absent_parameters_and_close():
+    """Buckets break where the top-level sub-module changes; a parameter that got no gradient in a step (the
+    reference's unused ``bn``) stops counting towards its bucket's readiness; announcing a gradient after its bucket
+    went out raises; close() detaches the reducer from the global gradient sinks."""
+    from avvad import dist as avd
+    from avvad import ops
+    names = ["features.0.weight", "features.1.weight", "bn.weight", "lstm.w", "lstm.b", "vad.weight"]
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (4000, 3000, 10, 5000, 100, 7)]
+    flat, offsets = avd.flat_views(ps)
+    red = avd.BucketReducer(ps, flat, offsets, bucket_bytes=1 << 30, names=names, min_group_bytes=1 << 10)
+    # features | bn (too small: rides with lstm) + lstm | vad (last)
+    assert [b[2] for b in red.buckets] == [2, 3, 1], red.buckets
+    red.world = 2                                              # pretend: exercise the bookkeeping without a process group
+    launched = []
+    red._launch = lambda b: None if red.launched[b] else (launched.append(b), red.launched.__setitem__(b, True))
+    for p in (ps[5], ps[4], ps[3], ps[1], ps[0]):              # backward order; bn.weight never shows up
+        red._on_grad(p)
+    assert launched == [2, 0]
+    red.handles = []
+    red.finish()                                               # launches bucket 1, learns that bn.weight is absent
+    assert launched == [2, 0, 1] and red.expected == [2, 2, 1] and id(ps[2]) in red.absent
+    launched.clear()
+    for p in (ps[5], ps[4], ps[3]):
+        red._on_grad(p)
+    assert launched == [2, 1]                                  # now the middle bucket goes out from the hooks
+    with pytest.raises(RuntimeError):
+        red._on_grad(ps[2])                                    # late gradient for an already reduced bucket
+    red.finish()
+    red.world = 1
+    red._sink = red._on_grad
+    ops.GRAD_SINKS.append(red._sink)
+    n0 = len(ops.GRAD_SINKS)
+    red.close()
+    assert len(ops.GRAD_SINKS) == n0 - 1 and red._sink is None

@@ -270,7 +270,7 @@ def test_video_net_golden_eval_and_train():
 
 
 @pytest.mark.parametrize("training,streamk", [(True, False), (False, False), (True, True), (False, True)])
-def test_trunk_backward_vs_oracle(training, streamk, monkeypatch):
+def test_trunk_backward_vs_oracle(training, streamk, lib_options):
     """gradients of a random projection of the features w.r.t. every trunk parameter.
 
     streamk=False runs the engine with whole-tile scheduling (AVVAD_NO_STREAMK=all): bit-reproducible, and held to
@@ -283,8 +283,7 @@ def test_trunk_backward_vs_oracle(training, streamk, monkeypatch):
     from oracle import resnet18
     from avvad import nn as avnn
     from packages.models.Video_Net import DeepVAD_video
-    if not streamk:
-        monkeypatch.setenv("AVVAD_NO_STREAMK", "all")
+    lib_options("no_streamk", 0 if streamk else 1)
     sd0 = _video_state()
     N = 6
     x = stategen.rand(21, N, 67, 67)
@@ -299,7 +298,7 @@ def test_trunk_backward_vs_oracle(training, streamk, monkeypatch):
     f = avnn.trunk_forward(m.features, x.to(DEV), training)
     _report("trunk fwd (training=%s, streamk=%s)" % (training, streamk), f, ref, 1e-4, 1e-5)
     (f * G.to(DEV)).sum().backward()
-    rel = 2e-2 if streamk else (5e-3 if training else 2e-3)
+    rel = 1e-2 if streamk else (5e-3 if training else 2e-3)
     for k, p in m.features.named_parameters():
         _report_grad("trunk d/d%s" % k, p.grad, sd["features." + k].grad, 2.0, rel)
 
@@ -350,15 +349,15 @@ def test_av_net_mcb_fusion_vs_oracle():
         _report(tag + " logits", y, ref, 1e-4)
         loss = batch_binary_cross_entropy(y, tgt.to(DEV), lens, 1e-8)
         loss.backward()
-        _report_grad(tag + " d/d audio", ag.grad, ar.grad, 2.0, 2e-2)
+        _report_grad(tag + " d/d audio", ag.grad, ar.grad, 2.0, 1e-2)
         for k in ("mcb_bn.weight", "mcb_bn.bias", "lstm_merged.weight_ih_l0", "features.7.1.conv2.weight", "features.0.weight"):
-            _report_grad(tag + " d/d" + k, dict(mg.named_parameters())[k].grad, sd[k].grad, 2.0, 2e-2)
+            _report_grad(tag + " d/d" + k, dict(mg.named_parameters())[k].grad, sd[k].grad, 2.0, 1e-2)
         if training:
             _report(tag + " running_var", mg.mcb_bn.running_var, sd["mcb_bn.running_var"], 1e-6, 1e-4)
             assert int(mg.mcb_bn.num_batches_tracked) == 1
     from avvad import AvvadError
     with pytest.raises(AvvadError):
-        mg.mcb(ag, ag)            # the bare containers have no stand-alone kernel and no fallback
+        mg.mcb(ag.cpu(), ag.cpu())            # the bare modules run on the GPU only: no PyTorch fallback
 
 
 def test_av_wavenet_end_to_end_vs_oracle():
@@ -391,7 +390,7 @@ def test_av_wavenet_end_to_end_vs_oracle():
         if p.grad is None:
             assert k.startswith("bn."), k          # the unused BatchNorm1d of the reference
             continue
-        _report_grad("AV+WaveNet d/d" + k, p.grad, sd[k].grad, 2.0, 2e-2)   # train-mode BN on 12 frames: see trunk test
+        _report_grad("AV+WaveNet d/d" + k, p.grad, sd[k].grad, 2.0, 1e-2)   # train-mode BN on 12 frames: see trunk test
 
 
 # ------------------------------------------------------------------------------------------ entry points
@@ -422,7 +421,7 @@ def test_train_and_evaluate_entry_points(tmp_path, monkeypatch):
     outs = sorted(os.listdir(tmp_path / "e"))
     assert outs == sorted(["utt%04d_%s.pt" % (i, k) for i in range(3) for k in ("y_hat_hard", "y_hat_soft", "label")])
     soft = torch.load(tmp_path / "e" / "utt0000_y_hat_soft.pt", weights_only=True)
-    assert soft.shape == (16, 1) and float(soft.min()) >= 0 and float(soft.max()) <= 1
+    assert soft.shape == (1, 16) and float(soft.min()) >= 0 and float(soft.max()) <= 1
     # run_metrics: per-utterance accuracy / precision / recall / F1 -> mean +- Student-t half-width
     stats = T.metrics_main(str(tmp_path / "e"))
     assert set(stats["all"]) == {"accuracy", "precision", "recall", "f1score"}
@@ -498,6 +497,169 @@ def test_stft_frontend_gpu(L):
         stft_pytorch(x.to(DEV), fs=16e3, wlen_sec=64e-3, win=torch.ones(1024, device=DEV), center=False)
 
 
+# ------------------------------------------------------------------------------------------ boundary: bare modules, losses
+def test_count_sketch_and_compact_bilinear_pooling_modules():
+    """``CountSketch.forward`` / ``CompactBilinearPooling.forward`` as stand-alone modules (compact_bilinear_pooling.py
+    :59-114,222-263): the sketch against the reference's own output (pinned fixture ``cs_y`` / ``cs_dx``), the pooled
+    vector + both input gradients against the oracle's FFT form (itself pinned to the naive outer-product definition)."""
+    from oracle import fusion
+    from packages.models.compact_bilinear_pooling import CompactBilinearPooling, CountSketch
+    g = load_golden("misc")
+    cs = CountSketch(513, 1024, T(g["cs_h"]), T(g["cs_s"])).to(DEV)
+    x = T(g["cs_x"]).to(DEV).requires_grad_(True)
+    y = cs(x)
+    _report("CountSketch.forward vs reference", y, g["cs_y"], 1e-6)
+    (y * T(g["cs_g"]).to(DEV)).sum().backward()
+    _report("CountSketch backward vs reference", x.grad, g["cs_dx"], 1e-6)
+    rng = np.random.RandomState(5)
+    h1, h2 = T(rng.randint(0, 1024, 513)), T(rng.randint(0, 1024, 512))
+    s1 = T((2 * rng.randint(0, 2, 513) - 1).astype(np.float32))
+    s2 = T((2 * rng.randint(0, 2, 512) - 1).astype(np.float32))
+    a, v, G = stategen.rand(61, 2, 3, 513), stategen.rand(62, 2, 3, 512), stategen.rand(63, 2, 3, 1024)
+    ar, vr = a.clone().requires_grad_(True), v.clone().requires_grad_(True)
+    ref = fusion.mcb(ar, vr, h1, s1, h2, s2, 1024)
+    (ref * G).sum().backward()
+    m = CompactBilinearPooling(513, 512, 1024, h1, s1, h2, s2).to(DEV)
+    ag, vg = a.to(DEV).requires_grad_(True), v.to(DEV).requires_grad_(True)
+    out = m(ag, vg)
+    _report("CompactBilinearPooling.forward", out, ref, 2e-4, 1e-5)
+    (out * G.to(DEV)).sum().backward()
+    _report_grad("CompactBilinearPooling d/dx", ag.grad, ar.grad)
+    _report_grad("CompactBilinearPooling d/dy", vg.grad, vr.grad)
+    sq = CompactBilinearPooling(513, 513, 1024, h1, s1, T(rng.randint(0, 1024, 513)), s1.clone()).to(DEV)
+    _report("CompactBilinearPooling(x) == (x, x)", sq(ag.detach()), sq(ag.detach(), ag.detach()), 0.0)
+
+
+def test_bce_2classes_vs_reference():
+    from packages.models.utils import binary_cross_entropy_2classes
+    g = load_golden("misc")
+    r1 = T(g["bce2_r1"]).to(DEV).requires_grad_(True)
+    r2 = T(g["bce2_r2"]).to(DEV).requires_grad_(True)
+    loss = binary_cross_entropy_2classes(r1, r2, T(g["bce2_x"]).to(DEV), 1e-8)
+    _report("bce_2classes", loss, g["bce2"], 1e-6)
+    (loss * 3.0).backward()
+    _report("bce_2classes d/dr1", r1.grad, 3.0 * g["bce2_d1"], 1e-6, 1e-5)
+    _report("bce_2classes d/dr2", r2.grad, 3.0 * g["bce2_d2"], 1e-6, 1e-5)
+
+
+@pytest.mark.parametrize("frozen", [("dil_w",), ("dense_w",), ("dil_w", "dense_w"), ("dil_b", "dense_b"), ("bott_w",)])
+def test_wavenet_partially_frozen_blocks(frozen):
+    """Gradients of a residual block are wanted independently: freezing one weight (or both weights but not the biases)
+    must leave the others exact (the fused MFMA backward once skipped them all and still returned OK)."""
+    from oracle import wavenet as ow
+    from packages.models.wavenet_autoencoder import wavenet_autoencoder
+    cfg = dict(filter_width=2, quantization_channel=1, dilations=[1, 2, 4], en_residual_channel=32,
+               en_dilation_channel=32, en_bottleneck_width=256, en_pool_kernel_size=5, use_bias=True)
+    torch.manual_seed(4)
+    m = wavenet_autoencoder(**cfg)
+    x = torch.randn(3, 1, 200)
+    G = torch.randn(3, 256, 5)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    (ow.encode(sd, x, cfg) * G).sum().backward()
+    pick = {"dil_w": "en_dilation_layer_stack.1.weight", "dense_w": "en_dense_layer_stack.1.weight",
+            "dil_b": "en_dilation_layer_stack.1.bias", "dense_b": "en_dense_layer_stack.1.bias", "bott_w": "bottleneck_layer.weight"}
+    frozen_keys = {pick[f] for f in frozen}
+    m = m.to(DEV)
+    for k, p in m.named_parameters():
+        p.requires_grad = k not in frozen_keys
+    (m(x.to(DEV)) * G.to(DEV)).sum().backward()
+    for k, p in m.named_parameters():
+        if k in frozen_keys:
+            assert p.grad is None, k
+        else:
+            _report_grad("frozen %s: d/d%s" % ("+".join(frozen), k), p.grad, sd[k].grad)
+
+
+def test_stem_maxpool_ties_follow_torch():
+    """Flat image regions give identical stem outputs, i.e. exact positive ties inside a 3x3 pooling window: torch
+    routes the gradient to the FIRST maximum in scan order only (its saved argmax); counting every tied element once
+    per window inflated the stem gradients."""
+    from oracle import resnet18
+    from avvad import nn as avnn
+    from packages.models.Video_Net import DeepVAD_video
+    sd0 = _video_state()
+    N = 4
+    x = stategen.rand(31, N, 67, 67)
+    x[0] = 0.7                                  # constant frame: every interior stem output of a channel is identical
+    x[1, :40] = -0.3                            # constant band (black border)
+    x[2, :, 20:] = 1.5
+    G = stategen.rand(32, N, 512)
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+          for k, v in sd0.items() if k.startswith("features.")}
+    ref = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), False)
+    (ref * G).sum().backward()
+    m = DeepVAD_video(2, 16, 1)
+    m.load_state_dict(sd0)
+    m = m.to(DEV).eval()
+    f = avnn.trunk_forward(m.features, x.to(DEV), False)
+    _report("trunk fwd with flat regions", f, ref, 1e-4, 1e-5)
+    (f * G.to(DEV)).sum().backward()
+    for k in ("0.weight", "1.weight", "1.bias"):
+        _report_grad("tie-breaking: trunk d/d%s" % k, dict(m.features.named_parameters())[k].grad, sd["features." + k].grad, 2.0, 2e-3)
+
+
+# ------------------------------------------------------------------------------------------ C1: evaluate_audio_net plumbing, K19
+def test_audio_evaluator_plumbing_on_a_real_utterance(tmp_path):
+    """BASELINE configs[0] plumbing (scripts/evaluate_audio_net.py:107-180) on one utterance of the reference's
+    data/subset: x/max|x| -> STFT -> power -> log -> crop -> standardise -> classifier -> sigmoid -> threshold, every
+    arithmetic step on the GPU, against (a) the oracle's features and (b) the logits / soft / hard outputs the
+    REFERENCE's own DeepVAD_audio produced from a checkpoint it wrote (tests/golden/audio_ref_h32_*.pt), for the VAD
+    head and the IBM head (y_dim 513).  The STFT itself is pinned only to the oracle restatement (torch 2.x cannot run
+    stft_pytorch): "parity unpinned" for that stage."""
+    from conftest import GOLDEN
+    from avvad import train as TR
+    from oracle import frontend
+    from packages.models.Audio_Net import DeepVAD_audio
+    g = load_golden("eval_audio")
+    wav = os.path.join(GOLDEN, "utt_sa1.npz")
+    x_t, fs = TR.load_waveform(wav)
+    stats = TR.Stats(audio_mean=g["mean"], audio_std=g["std"])
+    n_label = int(g["n_label"])
+    feats = TR.audio_features(x_t.to(DEV), stats, n_label)
+    ref_feats = frontend.audio_features(x_t, T(g["mean"]), T(g["std"]), n_label)
+    _report("evaluator features (1,180,513)", feats, ref_feats, 2e-3, 1e-4)     # log of a 1024-term fp32 DFT power
+    for tag, ydim in (("y1", 1), ("y513", 513)):
+        ck = os.path.join(GOLDEN, "audio_ref_h32_%s.pt" % tag)
+        out = tmp_path / tag
+        lab = torch.zeros(ydim, n_label)
+        TR.evaluate_main("audio", lambda: DeepVAD_audio(2, 32, ydim), checkpoint=ck, out_dir=str(out), wav_list=[wav],
+                         stats=stats, labels={wav: lab})
+        soft = torch.load(out / "utt_sa1_y_hat_soft.pt", weights_only=True)
+        hard = torch.load(out / "utt_sa1_y_hat_hard.pt", weights_only=True)
+        assert soft.shape == (1, n_label) and hard.dtype == torch.int32
+        _report("evaluator soft output (%s)" % tag, soft, g["soft_" + tag], 1e-4)
+        flips = int((hard.numpy() != g["hard_" + tag]).sum())
+        margin = np.abs(g["soft_" + tag] - 0.5)
+        assert flips == 0 or float(margin[hard.numpy() != g["hard_" + tag]].max()) < 1e-4, flips
+        m = DeepVAD_audio(2, 32, ydim)
+        m.load_state_dict(torch.load(ck, map_location="cpu", weights_only=True))
+        y = m.to(DEV).eval()(feats, [n_label])
+        _report("DeepVAD_audio(y_dim=%d) logits vs reference" % ydim, y, g["logits_" + tag], 1e-4)
+
+
+def test_input_standardisation_in_the_train_loop():
+    """K19: ``(x - mean.T) / (std + eps).T`` on audio features (513 per-bin statistics) and video (scalar statistics)
+    as applied by ``forward_batch`` (scripts/train_AV_net.py:286-291) vs the oracle."""
+    from avvad import train as TR
+    from oracle import frontend
+    a, v = stategen.rand(71, 3, 5, 513), stategen.rand(72, 3, 5, 67, 67)
+    am, as_ = stategen.rand(73, 513, 1), stategen.rand(74, 513, 1).abs() + 0.5
+    vm, vs = torch.tensor([[0.4]]), torch.tensor([[2.5]])
+    st = TR.Stats(am.numpy(), as_.numpy(), vm.numpy(), vs.numpy())
+    _report("standardise audio", st.audio(a.to(DEV)), frontend.standardize(a, am, as_), 1e-6, 1e-6)
+    _report("standardise video", st.video(v.to(DEV)), (v - vm.T) / (vs + 1e-8).T, 1e-6, 1e-6)
+    seen = {}
+
+    class Probe(torch.nn.Module):
+        def forward(self, x, vid, lengths):
+            seen["a"], seen["v"] = x, vid
+            return x[..., :1]
+    batch = (torch.LongTensor([5, 5, 5]), a, v, torch.zeros(3, 5, 1))
+    TR.forward_batch(Probe(), "av", batch, torch.device(DEV), False, st)
+    _report("forward_batch standardises audio", seen["a"], frontend.standardize(a, am, as_), 1e-6, 1e-6)
+    _report("forward_batch standardises video", seen["v"], (v - vm.T) / (vs + 1e-8).T, 1e-6, 1e-6)
+
+
 # ------------------------------------------------------------------------------------------ BASELINE-size properties
 def _max_rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
@@ -518,6 +680,101 @@ def test_full_size_c2_wavenet_batch_split():
         parts = torch.cat([m(x[i:i + 64]) for i in range(0, 256, 64)])
     assert full.shape == (256, 256, 60) and torch.isfinite(full).all()
     assert _max_rel(full, parts) == 0.0          # the forward encoder is deterministic and batch-independent
+
+
+def test_full_size_c2_wavenet_training_backward():
+    """BASELINE configs[1]: audio_net TRAINING at batch 256 of one-second chunks -- forward AND backward at full size
+    (21 activation planes of 524 MB each in the workspace).  Checks: (a) sequence 0 is the reference's own ``wn_w0``
+    sample, so its output row must equal the fixture; (b) shard-sum: the gradient of every parameter over the batch of
+    256 equals the sum over four shards of 64 (sequences are independent, the loss is a plain sum); (c) the input
+    gradient of sequence 0 equals the fixture's ``dx``."""
+    from packages.models.wavenet_autoencoder import wavenet_autoencoder
+    g = load_golden("wn_w0")
+    cfg = wn_cfg_from(g)
+    m = wavenet_autoencoder(**cfg)
+    m.load_state_dict({k[2:]: T(v) for k, v in g.items() if k.startswith("p.")})
+    m = m.to(DEV)
+    B = 256
+    torch.manual_seed(0)
+    x = torch.rand(B, 1, 16000, device=DEV) - 0.5
+    x[0] = T(g["x"]).to(DEV)[0]
+    G = torch.randn(B, 256, 60, device=DEV) * 0.1
+    G[0] = T(g["G"]).to(DEV)[0]
+    params = list(m.parameters())
+
+    def run(sl):
+        for p in params:
+            p.grad = None
+        xi = x[sl].clone().requires_grad_(True)
+        y = m(xi)
+        (y * G[sl]).sum().backward()
+        torch.cuda.synchronize()
+        return y.detach(), xi.grad.detach(), [p.grad.clone() for p in params]
+
+    y, dx, gf = run(slice(0, B))
+    assert y.shape == (B, 256, 60) and torch.isfinite(y).all() and torch.isfinite(dx).all()
+    _report("C2 B=256: sequence 0 forward == wn_w0 fixture", y[:1], g["y"], 1e-4)
+    _report_grad("C2 B=256: sequence 0 d/dx == wn_w0 fixture", dx[:1], g["dx"])
+    acc = [torch.zeros_like(t, dtype=torch.float64) for t in gf]
+    for i in range(0, B, 64):
+        yi, dxi, gi = run(slice(i, i + 64))
+        assert _max_rel(yi, y[i:i + 64]) == 0.0 and _max_rel(dxi, dx[i:i + 64]) < 1e-6
+        for a_, t in zip(acc, gi):
+            a_ += t.double()
+    for (k, _), f, a_ in zip(m.named_parameters(), gf, acc):
+        rel = float((f.double() - a_).norm() / a_.norm().clamp_min(1e-30))
+        print("C2 shard-sum d/d%-40s relL2 %.2e" % (k, rel))
+        assert rel < 1e-4, (k, rel)             # only the fp32 summation order over (sequence, time) differs
+
+
+def test_full_size_c3_trunk_train_mode_backward(lib_options):
+    """BASELINE configs[2]: 512 lip crops through the trunk in TRAINING mode (batch statistics), forward + backward at
+    full size.  The oracle can afford this size once (about 0.7 TFLOP on the host cores): features, updated running
+    statistics and a spread of weight / BN gradients are compared on the full batch under the production schedule; then
+    a 6-frame slice of the same frames is re-run alone (eval-mode BatchNorm, whole-tile schedule: bit-reproducible)
+    and every gradient is held to the strict bounds."""
+    from oracle import resnet18
+    from avvad import nn as avnn
+    from packages.models.Video_Net import DeepVAD_video
+    sd0 = _video_state()
+    m = DeepVAD_video(2, 16, 1)
+    m.load_state_dict(sd0)
+    m = m.to(DEV).train()
+    N = 512
+    x = stategen.rand(41, N, 67, 67)
+    G = stategen.rand(42, N, 512)
+    f = avnn.trunk_forward(m.features, x.to(DEV), True)
+    (f * G.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    assert f.shape == (N, 512) and torch.isfinite(f).all()
+    for k, p in m.features.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+    sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+          for k, v in sd0.items() if k.startswith("features.")}
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ref = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), True)
+    (ref * G).sum().backward()
+    _report("C3 train-mode trunk fwd N=512", f, ref, 1e-4, 1e-5)
+    new = m.state_dict()
+    for k in ("features.1.running_mean", "features.1.running_var", "features.7.1.bn2.running_mean", "features.7.1.bn2.running_var"):
+        _report("C3 running stat " + k, new[k], sd[k], 1e-5, 1e-5)
+    for k in ("0.weight", "1.weight", "4.0.conv1.weight", "5.0.downsample.0.weight", "6.1.bn2.bias", "7.1.conv2.weight"):
+        _report_grad("C3 N=512 trunk d/d%s" % k, dict(m.features.named_parameters())[k].grad, sd["features." + k].grad, 2.0, 5e-3)
+    # (c) 6-frame slice alone, eval-mode BN, whole-tile schedule, strict bounds
+    lib_options("no_streamk", 1)
+    m2 = DeepVAD_video(2, 16, 1)
+    m2.load_state_dict(sd0)
+    m2 = m2.to(DEV).eval()
+    sl = x[100:106]
+    sd2 = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
+           for k, v in sd0.items() if k.startswith("features.")}
+    r2 = resnet18.trunk_forward(sd2, sl[:, None].repeat(1, 3, 1, 1), False)
+    (r2 * G[100:106]).sum().backward()
+    f2 = avnn.trunk_forward(m2.features, sl.to(DEV), False)
+    _report("C3 6-frame slice eval fwd", f2, r2, 1e-4, 1e-5)
+    (f2 * G[100:106].to(DEV)).sum().backward()
+    for k, p in m2.features.named_parameters():
+        _report_grad("C3 slice d/d%s" % k, p.grad, sd2["features." + k].grad, 2.0, 2e-3)
 
 
 def test_full_size_c3_trunk_batch_split_and_scale():
@@ -576,7 +833,7 @@ def test_full_size_c4_dp_shard_gradient_sum():
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])
-def test_two_rank_gpu_data_parallel_step(tmp_path, monkeypatch, overlap):
+def test_two_rank_gpu_data_parallel_step(tmp_path, lib_options, monkeypatch, overlap):
     """The N > 1 path on the real kernels: two processes (both on cuda:0, gradients exchanged through gloo -- RCCL
     refuses two ranks per device), each a shard of the batch; the SUM all-reduce of the flat gradient must equal the
     single-process gradient of the whole batch (loss is a sum over sequences; eval-mode BatchNorm so that shards are
@@ -596,19 +853,23 @@ def test_two_rank_gpu_data_parallel_step(tmp_path, monkeypatch, overlap):
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     out = str(tmp_path / "flat_grad.pt")
-    monkeypatch.setenv("AVVAD_NO_STREAMK", "all")
-    monkeypatch.setenv("AVVAD_OVERLAP", overlap)
-    env = dict(os.environ, AVVAD_DIST_BACKEND="gloo", AVVAD_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    from avvad import ops
+    lib_options("no_streamk", 1)                 # this process (the whole-batch reference run below) ...
+    monkeypatch.setattr(ops, "_OVERLAP", overlap == "1")
+    env = dict(os.environ, AVVAD_DIST_BACKEND="gloo", AVVAD_FORCE_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0",
+               AVVAD_NO_STREAMK="all", AVVAD_OVERLAP=overlap)      # ... and the workers (read once when they load the library)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), "dp_gpu_worker.py"), out]
     try:
-        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
-    except subprocess.TimeoutExpired:
-        pytest.skip("two-rank launch timed out on this box (rendezvous), nothing to compare")
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired as e:
+        # a hang in the two-rank path (collective order, a stream dependency) must read as a failure, not a skip
+        raise AssertionError("two-rank workers did not finish in 300 s:\n" + str(e.stderr or "")[-3000:])
     if r.returncode != 0 or not os.path.exists(out):
-        if "AssertionError" in r.stderr or "AvvadError" in r.stderr:
-            raise AssertionError("two-rank worker failed:\n" + r.stderr[-3000:])
-        pytest.skip("two-rank launch not possible on this box: " + r.stderr[-400:].replace("\n", " | "))
+        env_msgs = ("address already in use", "EADDRINUSE", "Gloo is not available", "gloo backend is not available")
+        if any(m.lower() in r.stderr.lower() for m in env_msgs):      # recognised environment problems only
+            pytest.skip("two-rank launch not possible on this box: " + r.stderr[-400:].replace("\n", " | "))
+        raise AssertionError("two-rank worker failed (exit %d):\n%s" % (r.returncode, r.stderr[-3000:]))
     got = torch.load(out, weights_only=True)
     model = case.make_model().to(DEV).eval()
     wave, video, target, lengths = [t.to(DEV) for t in case.make_batch()]

@@ -188,3 +188,46 @@ def test_metrics_tables_match_reference(capsys):
                                   all_metrics=[tuple(r) for r in per_utt], model_data_dir="", confidence=0.95, all_snr_db=g["snr"])
     assert capsys.readouterr().out == bytes(g["table"]).decode()
     assert stats["all"]["f1score"]["avg"] == g["ci"][6][0]
+
+
+def test_bce_2classes_and_count_sketch_backward_vs_reference():
+    """``binary_cross_entropy_2classes`` (models/utils.py:115-116) value + gradients and ``CountSketchFn_backward``
+    (compact_bilinear_pooling.py:30-38) as the reference computed them."""
+    g = load_golden("misc")
+    r1 = T(g["bce2_r1"]).clone().requires_grad_(True)
+    r2 = T(g["bce2_r2"]).clone().requires_grad_(True)
+    l = head.bce_2classes(r1, r2, T(g["bce2_x"]), 1e-8)
+    np.testing.assert_allclose(l.item(), g["bce2"], rtol=1e-6)
+    l.backward()
+    np.testing.assert_allclose(r1.grad.numpy(), g["bce2_d1"], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r2.grad.numpy(), g["bce2_d2"], rtol=1e-5, atol=1e-7)
+    x = T(g["cs_x"]).clone().requires_grad_(True)
+    y = fusion.count_sketch(x, T(g["cs_h"]), T(g["cs_s"]), 1024)
+    (y * T(g["cs_g"])).sum().backward()
+    np.testing.assert_array_equal(x.grad.numpy(), g["cs_dx"])
+
+
+@pytest.mark.parametrize("tag,ydim", [("y1", 1), ("y513", 513)])
+def test_reference_checkpoint_and_ibm_head(tag, ydim):
+    """N4: the ``.pt`` written by ``torch.save(DeepVAD_audio(2, 32, y_dim).state_dict())`` of the REFERENCE class loads
+    (weights_only) and the oracle reproduces the reference's logits on the evaluator's features of a real utterance,
+    for the VAD head (y_dim 1) and the IBM head (y_dim 513, ``train_AV_net.py:65-66``)."""
+    import os
+    from conftest import GOLDEN
+    from avvad.train import load_waveform
+    g = load_golden("eval_audio")
+    sd = torch.load(os.path.join(GOLDEN, "audio_ref_h32_%s.pt" % tag), map_location="cpu", weights_only=True)
+    x_t, fs = load_waveform(os.path.join(GOLDEN, "utt_sa1.npz"))
+    assert fs == 16000 and x_t.dtype == torch.float32 and float(x_t.abs().max()) <= 1.0
+    feats = frontend.audio_features(x_t, T(g["mean"]), T(g["std"]), int(g["n_label"]))
+    assert tuple(feats.shape) == tuple(g["feats_shape"]) == (1, 180, 513)
+    y = models.audio_net(sd, feats, [feats.shape[1]], 2)
+    assert y.shape == (1, 180, ydim)
+    np.testing.assert_allclose(y.numpy(), g["logits_" + tag], rtol=0, atol=5e-6)
+    soft = torch.sigmoid(y[..., 0])
+    np.testing.assert_allclose(soft.numpy(), g["soft_" + tag], atol=2e-6)
+    # the drop-in class takes the same file (CPU load only: its forward needs the GPU)
+    from packages.models.Audio_Net import DeepVAD_audio
+    m = DeepVAD_audio(2, 32, ydim)
+    m.load_state_dict(sd)
+    assert m.vad_audio.weight.shape == (ydim, 32)

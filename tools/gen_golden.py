@@ -40,7 +40,7 @@ from packages.models.wavenet_autoencoder import wavenet_autoencoder  # noqa: E40
 from packages.models.Audio_Net import DeepVAD_audio  # noqa: E402
 from packages.models.Video_Net import DeepVAD_video  # noqa: E402
 from packages.models.AV_Net import DeepVAD_AV  # noqa: E402
-from packages.models.compact_bilinear_pooling import CountSketch  # noqa: E402
+from packages.models.compact_bilinear_pooling import CountSketch, CountSketchFn_backward  # noqa: E402
 from packages.models import utils as ref_mutils  # noqa: E402
 from packages import utils as ref_utils  # noqa: E402
 
@@ -210,6 +210,15 @@ def gen_misc():
     cs = CountSketch(513, 1024, h.clone(), s.clone())
     cx = stategen.rand(41, 2, 3, 513)
     arrs["cs_h"], arrs["cs_s"], arrs["cs_x"], arrs["cs_y"] = npy(h), npy(s), npy(cx), npy(cs(cx))
+    cg = stategen.rand(43, 2, 3, 1024)
+    arrs["cs_g"], arrs["cs_dx"] = npy(cg), npy(CountSketchFn_backward(h, s, tuple(cx.shape), cg))
+    # two-output-unit BCE on probabilities (imported by train_video_net.py:18)
+    r1 = torch.sigmoid(stategen.rand(44, 6, 3)).requires_grad_(True)
+    r2 = torch.sigmoid(stategen.rand(45, 6, 3)).requires_grad_(True)
+    bx = (stategen.rand(46, 6, 3) > 0).float()
+    l2 = ref_mutils.binary_cross_entropy_2classes(r1, r2, bx, 1e-8)
+    l2.backward()
+    arrs.update(bce2_r1=npy(r1), bce2_r2=npy(r2), bce2_x=npy(bx), bce2=npy(l2), bce2_d1=npy(r1.grad), bce2_d2=npy(r2.grad))
     # method3
     from torch.nn.utils.rnn import pack_padded_sequence
     seq = stategen.rand(42, 4, 5, 6)
@@ -244,6 +253,36 @@ def gen_misc():
          av=np.array(ref_utils.count_parameters(DeepVAD_AV(2, 1024, 1))))
 
 
+# ------------------------------------------------------------------ N4 / C1: IBM head (y_dim = 513), a checkpoint written by the
+# reference's own class, and one real utterance of data/subset through the evaluator's plumbing
+def gen_eval():
+    from scipy.io import wavfile
+    from oracle import frontend
+    fs, wav = wavfile.read(os.path.join(REF, "data/subset/processed/ntcd_timit/Noisy/Babble/-5/test/34M/sa1.wav"))
+    assert fs == 16000 and wav.dtype == np.int16 and wav.ndim == 1
+    wav = wav[:3 * 16000 + 100]                              # 3 s (+100 samples: the one-hop end-pad branch is taken)
+    np.savez_compressed(os.path.join(OUT, "utt_sa1.npz"), samples=wav, fs=np.array(fs))
+    x_t = torch.from_numpy(wav.astype(np.float32) / 32768.0)
+    mean = stategen.rand(400, 513, 1) * 2.0 - 6.0
+    std = stategen.rand(401, 513, 1).abs() + 1.5
+    n_label = 180                                            # label shorter than the STFT: frames are cropped (:144-146)
+    feats = frontend.audio_features(x_t, mean, std, n_label)  # oracle restatement (stft_pytorch cannot run on torch 2.x)
+    arrs = dict(mean=npy(mean), std=npy(std), n_label=np.array(n_label), feats_shape=np.array(feats.shape))
+    for tag, ydim in (("y1", 1), ("y513", 513)):
+        torch.manual_seed(500 + ydim)
+        m = DeepVAD_audio(2, 32, ydim)                       # the REFERENCE class; default torch init
+        path = os.path.join(OUT, "audio_ref_h32_%s.pt" % tag)
+        torch.save(m.state_dict(), path)                     # the checkpoint format of train_audio_net.py:367-372
+        m.eval()
+        y = m(feats, [feats.shape[1]])
+        soft = torch.sigmoid(y[..., 0].detach())
+        arrs["logits_" + tag] = npy(y)
+        arrs["soft_" + tag] = npy(soft)
+        arrs["hard_" + tag] = npy((soft > 0.5).int())
+        print("%-28s %8.1f KB" % (os.path.basename(path), os.path.getsize(path) / 1024))
+    save("eval_audio", **arrs)
+
+
 # ------------------------------------------------------------------ reporting: confidence intervals / stats tables
 def gen_metrics():
     import contextlib
@@ -264,6 +303,6 @@ def gen_metrics():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["wavenet", "audio", "video", "av", "misc", "metrics"]
+    which = sys.argv[1:] or ["wavenet", "audio", "video", "av", "misc", "metrics", "eval"]
     for w in which:
         globals()["gen_" + w]()
