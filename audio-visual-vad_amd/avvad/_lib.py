@@ -80,17 +80,20 @@ SIGNATURES = {
     "avvad_abi_version": (C.c_int, []),
     "avvad_set_option": (C.c_int, [C.c_char_p, C.c_int]),
     "avvad_get_option": (C.c_int, [C.c_char_p]),
-    "avvad_gemm_f32": (C.c_int, [FP, FP, FP, FP, C.POINTER(GemmDesc), FP]),
+    "avvad_engine_workspace": (C.c_size_t, []),
+    "avvad_gemm_f32": (C.c_int, [FP, FP, FP, FP, C.POINTER(GemmDesc), FP, C.c_size_t, FP]),
     "avvad_wavenet_workspace": (C.c_size_t, [C.POINTER(WavenetDesc)]),
     "avvad_wavenet_fwd": (C.c_int, [FP, C.POINTER(WavenetPtrs), FP, C.POINTER(WavenetDesc), FP, C.c_size_t, FP]),
     "avvad_wavenet_bwd": (C.c_int, [FP, C.POINTER(WavenetPtrs), FP, C.POINTER(WavenetPtrs), FP,
                                     C.POINTER(WavenetDesc), FP, C.c_size_t, FP]),
     "avvad_wavenet_block_fwd": (C.c_int, [FP, FP, FP, FP, FP, FP, C.c_int, C.c_int, C.c_int, FP]),
     "avvad_conv2d_pack_weights": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
-    "avvad_conv2d_fwd": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
-    "avvad_conv2d_dgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), C.c_int, FP]),
-    "avvad_conv2d_wgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
+    "avvad_conv2d_fwd": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP, C.c_size_t, FP]),
+    "avvad_conv2d_dgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), C.c_int, FP, C.c_size_t, FP]),
+    "avvad_conv2d_wgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP, C.c_size_t, FP]),
     "avvad_trunk_workspace": (C.c_size_t, [C.POINTER(TrunkDesc)]),
+    "avvad_trunk_activation": (C.c_int, [C.POINTER(TrunkDesc), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                         C.POINTER(C.c_int)]),
     "avvad_trunk_fwd": (C.c_int, [FP, C.POINTER(TrunkParams), FP, C.POINTER(TrunkDesc), FP, C.c_size_t, FP]),
     "avvad_trunk_bwd": (C.c_int, [FP, C.POINTER(TrunkParams), FP, C.POINTER(TrunkGrads), C.POINTER(TrunkDesc), FP,
                                   C.c_size_t, FP]),

@@ -101,9 +101,17 @@ def lengths_i32(lengths, device):
 
 
 # --------------------------------------------------------------------------- GEMM / Linear
+def engine_ws(device):
+    """Scratch of the GEMM engine (partial tiles of its stream-K round): caller-allocated per call, like every
+    workspace of the C ABI; torch's caching allocator makes that a pointer bump."""
+    return torch.empty(L.lib().avvad_engine_workspace() // 4, dtype=torch.float32, device=device)
+
+
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, transA=False, transB=False, bias=None, accumulate=False, split_k=1):
     d = L.GemmDesc(M, N, K, lda, ldb, ldc, int(transA), int(transB), int(accumulate), split_k, 0, 0)
-    L.check(L.lib().avvad_gemm_f32(L.ptr(A), L.ptr(B), L.ptr(bias), L.ptr(C_out), C.byref(d), _stream()), "avvad_gemm_f32")
+    ws = engine_ws(C_out.device)
+    L.check(L.lib().avvad_gemm_f32(L.ptr(A), L.ptr(B), L.ptr(bias), L.ptr(C_out), C.byref(d), L.ptr(ws), ws.numel() * 4,
+                                   _stream()), "avvad_gemm_f32")
 
 
 class LinearFn(torch.autograd.Function):
@@ -312,6 +320,36 @@ class TrunkFn(torch.autograd.Function):
                                         L.ptr(ws), ws.numel() * 4, _stream()), "avvad_trunk_bwd")
         grads = _finish_grads(ctx.owners[:3 * n], tg)
         return (None, None, None, None) + tuple(grads) + (None,) * (2 * n)
+
+
+def trunk_saved_activations(feat):
+    """Test support: the post-ReLU activations kept for backward by the TrunkFn node behind ``feat``, as a dict
+    name -> (N,C,H,W) view: ``pool``, ``<stage>.<block>.a1``, ``<stage>.<block>`` (the oracle's names)."""
+    todo, seen, node = [feat.grad_fn], set(), None          # breadth-first over the autograd graph behind `feat`
+    while todo:
+        f = todo.pop(0)
+        if f is None or f in seen:
+            continue
+        seen.add(f)
+        if type(f).__name__ == "TrunkFnBackward":
+            node = f
+            break
+        todo.extend(nf for nf, _ in f.next_functions)
+    if node is None:
+        raise L.AvvadError("no TrunkFn node behind this tensor (was the forward run with gradients enabled?)")
+    frames, ws = node.saved_tensors[0], node.saved_tensors[1]
+    N, H, W = frames.shape
+    training, momentum, eps = node.cfg
+    d = L.TrunkDesc(N, H, W, training, momentum, eps, 1)
+    out = {}
+    for idx in range(17):
+        off, c, h, w = C.c_size_t(), C.c_int(), C.c_int(), C.c_int()
+        L.check(L.lib().avvad_trunk_activation(C.byref(d), idx, C.byref(off), C.byref(c), C.byref(h), C.byref(w)), "avvad_trunk_activation")
+        t = ws[off.value: off.value + N * h.value * w.value * c.value].view(N, h.value, w.value, c.value).permute(0, 3, 1, 2)
+        k = (idx - 1) // 2
+        name = "pool" if idx == 0 else "%d.%d%s" % (4 + k // 2, k % 2, ".a1" if (idx - 1) % 2 == 0 else "")
+        out[name] = t
+    return out
 
 
 # --------------------------------------------------------------------------- MCB fusion

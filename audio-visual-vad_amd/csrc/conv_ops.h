@@ -175,7 +175,8 @@ struct ColSegRows {
     return ok;
   }
 };
-// epilogue: class-local row m -> input pixel (n, 2i+ph, 2j+pw); always accumulating (the caller zero-fills)
+// epilogue: class-local row m -> input pixel (n, 2i+ph, 2j+pw); always accumulating (the caller zero-fills; plain RMW:
+// the four parity classes write disjoint pixels and run one after the other on the stream)
 struct EpiS2 {
   float* C;
   long ldc;
@@ -184,14 +185,12 @@ struct EpiS2 {
   int cs;
   int H, W, Hc, Wc, ph, pw;
   unsigned mg_hw, mg_wc;   // div_magic(Hc*Wc), div_magic(Wc)
-  __device__ __forceinline__ float* at(int m, int n) const {
+  __device__ __forceinline__ float* ptr(int m, int n) const {
     const int hw = Hc * Wc;
     const int img = fast_div(m, mg_hw), r = m - img * hw;
     const int i = fast_div(r, mg_wc), j = r - i * Wc;
     return C + ((long)(img * H + 2 * i + ph) * W + 2 * j + pw) * ldc + n;
   }
-  __device__ __forceinline__ void store(int m, int n, float v) const { *at(m, n) += v; }
-  __device__ __forceinline__ void add_partial(int m, int n, float v) const { atomicAdd(at(m, n), v); }
 };
 
 // packed weights [(tap, ch)][x] read in (chunk, tap, channel) K order: k = (cc*T + tap)*32 + r -> row tap*C + cc*32 + r
@@ -214,21 +213,19 @@ struct ColTapRows {
     return ok;
   }
 };
-// wgrad epilogue: GEMM row m' = (cc*T + tap)*32 + r (chunk-major, see WgradX) -> packed row tap*C + cc*32 + r; atomic
+// wgrad epilogue: GEMM row m' = (cc*T + tap)*32 + r (chunk-major, see WgradX) -> packed row tap*C + cc*32 + r
 struct EpiWgrad {
   float* C;
   long ldc;
   const float* bias;  // unused
-  int mode;           // 2
+  int mode;           // 0: the packed gradient is overwritten (split tiles are combined by igemm::fixup)
   int cs;
   int Cch, T;
   unsigned mg_T;
-  __device__ __forceinline__ float* at(int m, int n) const {
+  __device__ __forceinline__ float* ptr(int m, int n) const {
     const int q = m >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;
     return C + (long)(tap * Cch + cc * 32 + (m & 31)) * ldc + n;
   }
-  __device__ __forceinline__ void store(int m, int n, float v) const { atomicAdd(at(m, n), v); }
-  __device__ __forceinline__ void add_partial(int m, int n, float v) const { atomicAdd(at(m, n), v); }
 };
 
 // ---- wgrad A: A[m][k = output pixel] = x[n, ho*s-p+kh, wo*s-p+kw, c] with m = (cc*T + tap)*32 + r, c = cc*32 + r:

@@ -7,53 +7,54 @@
 namespace {
 
 template <int BM, int BN, class AOp, class BOp>
-int run2(const AOp& a, const BOp& b, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s) {
-  return igemm::launch<BM, BN>(a, b, e, d->M, d->N, d->K, d->split_k, s);
+int run2(const AOp& a, const BOp& b, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s, float* slab) {
+  return igemm::launch<BM, BN>(a, b, e, d->M, d->N, d->K, d->split_k, s, slab);
 }
 
 template <class AOp, class BOp>
-int run1(const AOp& a, const BOp& b, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s) {
-  if (d->M <= 64 || d->N <= 64) return run2<64, 64>(a, b, e, d, s);
-  return run2<128, 128>(a, b, e, d, s);
+int run1(const AOp& a, const BOp& b, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s, float* slab) {
+  if (d->M <= 64 || d->N <= 64) return run2<64, 64>(a, b, e, d, s, slab);
+  return run2<128, 128>(a, b, e, d, s, slab);
 }
 
 template <class AOp>
-int runA(const AOp& a, const float* B, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s) {
+int runA(const AOp& a, const float* B, const igemm::EpiStore& e, const avvad_gemm_desc* d, hipStream_t s, float* slab) {
   if (d->transB) {  // stored [N][K]
     igemm::RowPlain b{B, d->ldb, d->N, d->K, d->relu_b};
-    return run1(a, b, e, d, s);
+    return run1(a, b, e, d, s, slab);
   }
   const bool v4 = (d->ldb % 4 == 0) && (d->N % 4 == 0) && ((uintptr_t)B % 16 == 0);
   if (v4) {
     igemm::ColPlain<4> b{B, d->ldb, d->N, d->K, d->relu_b};
-    return run1(a, b, e, d, s);
+    return run1(a, b, e, d, s, slab);
   }
   igemm::ColPlain<1> b{B, d->ldb, d->N, d->K, d->relu_b};
-  return run1(a, b, e, d, s);
+  return run1(a, b, e, d, s, slab);
 }
 
 }  // namespace
 
-int avvad_gemm_impl(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d, hipStream_t s) {
+int avvad_gemm_impl(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d, hipStream_t s, float* slab) {
   if (!A || !B || !C || !d || d->M <= 0 || d->N <= 0 || d->K <= 0) return AVVAD_EINVAL;
-  if (d->split_k > 1 && !d->accumulate) return AVVAD_EINVAL;  // partials are atomically added onto C
+  if (d->split_k > 1 && !d->accumulate) return AVVAD_EINVAL;  // historical: a K-split product accumulates onto C
   igemm::EpiStore e{C, d->ldc, bias, d->split_k > 1 ? 2 : (d->accumulate ? 1 : 0)};
   if (bias && d->split_k > 1) return AVVAD_EINVAL;
   if (!d->transA) {  // [M][K]
     igemm::RowPlain a{A, d->lda, d->M, d->K, d->relu_a};
-    return runA(a, B, e, d, s);
+    return runA(a, B, e, d, s, slab);
   }
   const bool v4 = (d->lda % 4 == 0) && (d->M % 4 == 0) && ((uintptr_t)A % 16 == 0);
   if (v4) {
     igemm::ColPlain<4> a{A, d->lda, d->M, d->K, d->relu_a};
-    return runA(a, B, e, d, s);
+    return runA(a, B, e, d, s, slab);
   }
   igemm::ColPlain<1> a{A, d->lda, d->M, d->K, d->relu_a};
-  return runA(a, B, e, d, s);
+  return runA(a, B, e, d, s, slab);
 }
 
-extern "C" int avvad_gemm_f32(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d,
-                              avvad_stream_t s) {
+extern "C" int avvad_gemm_f32(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d, void* ws,
+                              size_t ws_bytes, avvad_stream_t s) {
   AVVAD_ENTER();
-  return avvad_gemm_impl(A, B, bias, C, d, (hipStream_t)s);
+  float* slab = (ws && ws_bytes >= igemm::SLAB_FLOATS * sizeof(float)) ? (float*)ws : nullptr;
+  return avvad_gemm_impl(A, B, bias, C, d, (hipStream_t)s, slab);
 }

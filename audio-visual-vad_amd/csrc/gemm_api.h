@@ -3,7 +3,9 @@
 #pragma once
 #include "igemm.h"
 
-int avvad_gemm_impl(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d, hipStream_t s);
+// slab: igemm::SLAB_FLOATS floats of scratch (partial tiles of the stream-K round) or nullptr (whole-tile schedule)
+int avvad_gemm_impl(const float* A, const float* B, const float* bias, float* C, const avvad_gemm_desc* d, hipStream_t s,
+                    float* slab);
 
 static inline avvad_gemm_desc gemm_desc(int M, int N, int K, int lda, int ldb, int ldc, int tA, int tB, int acc, int split) {
   avvad_gemm_desc d;

@@ -31,22 +31,17 @@ constexpr int BK = 32;
 struct NoCtx {};
 
 // ---------------------------------------------------------------- epilogues
+// An epilogue names WHERE element (m, n) of the product lives (ptr) and HOW it lands there: mode 0 overwrite, mode 1/2
+// accumulate (C += v; 2 is the historical "K-split accumulate" spelling and means the same).  The kernel performs the
+// store itself.  No epilogue adds atomically any more: a tile whose K range is split between workers is combined by the
+// fix-up kernel below in a fixed order (bit-reproducible), the K-major tuning mode being the one exception.
 struct EpiStore {
   float* C;
   long ldc;
   const float* bias;  // per column n, may be null (added by the kernel: once per column, before the row loop)
-  int mode;           // 0 store, 1 C += v, 2 atomicAdd
+  int mode;           // 0 store, 1 / 2 C += v
   int cs = 1;         // column stride (elements)
-  __device__ __forceinline__ void store(int m, int n, float v) const {
-    float* p = C + (long)m * ldc + (long)n * cs;
-    if (mode == 0) *p = v;
-    else if (mode == 1) *p += v;
-    else atomicAdd(p, v);
-  }
-  // piece of a K-split tile: always an atomic add (the output is pre-zeroed or accumulating)
-  __device__ __forceinline__ void add_partial(int m, int n, float v) const {
-    atomicAdd(C + (long)m * ldc + (long)n * cs, v);
-  }
+  __device__ __forceinline__ float* ptr(int m, int n) const { return C + (long)m * ldc + (long)n * cs; }
 };
 
 // ---------------------------------------------------------------- dense operands
@@ -208,7 +203,7 @@ template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi>
 //  pinning them to their per_cu made the 64x64 kernels spill.)
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 128) ? 2 : 3))
     kernel(const AOp A, const BOp B, const Epi E, const int M, const int N, const int K, const int ktiles,
-           const int full_rounds, const int rem_tiles, const int kchunks) {
+           const int full_rounds, const int rem_tiles, const int kchunks, float* __restrict__ const slab) {
   typedef Stage<AOp, BM, NTH> SA;
   typedef Stage<BOp, BN, NTH> SB;
   // wave grid WGM x WGN: 2 x 2 (256 threads), 2 x 4 (512 threads, 128x128) or 4 x 2 (512 threads, 256x64: the tall tile
@@ -385,26 +380,48 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
       }
     }
 
-    const bool whole = (kt0 == 0 && kt1 == ktiles);
     const unsigned long long tp2 = PROF_T();
-    // Epilogue.  The column's bias is fetched once (a load + wait per element costs a memory round trip each).  Plain
+    // (the epilogue's lane-dependent index math must not be hoisted above the K loop: opaque copies of the lane
+    //  coordinates keep its address registers out of the loop's live set -- hoisted, they pushed the 8-wave kernels past
+    //  their 128-VGPR budget and the spills landed around every tile segment)
+    int li_e = li, lh_e = lh;
+    asm volatile("" : "+v"(li_e), "+v"(lh_e));
+    if (kchunks == 0 && kt0 > 0) {
+      // Piece of a split tile that does not start the tile's K range (at most ONE per worker: the first segment of its
+      // stream-K share): the raw partial sums go to this worker's slab, tile-local [BM][BN]; the fix-up kernel adds the
+      // slabs of a tile onto its output in ascending worker (= ascending K) order.  No atomics, no pre-zeroed output.
+      float* const S = slab + g * (long)(BM * BN);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = wn * (BN / WGN) + j * 32 + li_e;
+          const int rowb = wm * (BM / WGM) + i * 32 + 4 * lh_e;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) S[(rowb + mfma32_row(r, 0)) * BN + col] = acc[i][j][r];
+        }
+      continue;
+    }
+    // Whole tile, or the piece that starts the tile's K range (it owns the output until the fix-up kernel runs): plain
+    // stores.  The column's bias is fetched once (a load + wait per element costs a memory round trip each).  Plain
     // row-major outputs that fit 32-bit offsets take the fast path: interior tiles skip the per-element range checks
     // and every store is one v_add on a 32-bit offset against the scalar base (global_store_dword v, v, s[C]).
+    const bool atomic = kchunks > 0;       // K-major cells (tuning mode, off by default): several cells share a tile
     bool fast = false;
     if constexpr (std::is_same<Epi, EpiStore>::value) fast = E.cs == 1 && (long)M * E.ldc < (1L << 31) && m0 + BM <= M && n0 + BN <= N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn * (BN / WGN) + j * 32 + li;
+        const int n = n0 + wn * (BN / WGN) + j * 32 + li_e;
         const float bv = (E.bias && n < N && kt0 == 0) ? E.bias[n] : 0.f;
         const int mb = m0 + wm * (BM / WGM) + i * 32;
         if constexpr (std::is_same<Epi, EpiStore>::value) {
           if (fast) {
             const unsigned ld32 = (unsigned)E.ldc;
-            const unsigned base = (unsigned)(mb + 4 * lh) * ld32 + (unsigned)n;
+            const unsigned base = (unsigned)(mb + 4 * lh_e) * ld32 + (unsigned)n;
             float* const Cb = E.C;
-            if (!whole || E.mode == 2) {
+            if (atomic) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) atomicAdd(Cb + (base + (unsigned)mfma32_row(r, 0) * ld32), acc[i][j][r] + bv);
             } else if (E.mode == 0) {
@@ -422,10 +439,13 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int m = mb + mfma32_row(r, lh);
+          const int m = mb + mfma32_row(r, lh_e);
           if (m < M && n < N) {
-            if (whole) E.store(m, n, acc[i][j][r] + bv);
-            else E.add_partial(m, n, acc[i][j][r] + bv);
+            float* const p = E.ptr(m, n);
+            const float v = acc[i][j][r] + bv;
+            if (atomic) atomicAdd(p, v);
+            else if (E.mode == 0) *p = v;
+            else *p += v;
           }
         }
       }
@@ -443,20 +463,72 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
 #endif
 }
 
-static __global__ void zero_strided(float* C, int M, int N, long ldc, int cs) {
-  const long n = (long)M * N;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-    C[(i / N) * ldc + (i % N) * cs] = 0.f;
+// Fix-up of the stream-K round: tile tr of the remainder pool was cut between workers ga .. gb (ascending K).  Worker ga
+// stored (or accumulated) its piece onto the output, workers ga+1 .. gb left theirs in their slabs; this kernel adds those
+// slabs in a FIXED order -- so the result is bit-reproducible run to run.  It replaces both the zero-fill launch in front
+// of the GEMM and the float atomics inside it.
+// One workgroup = 4 waves per 256-element strip of a tile (lane = one float4): wave w sums the tile's slabs ga+1+w,
+// ga+1+w+4, ... with four loads in flight, the four partial sums meet in LDS in wave order.  (First version: one thread
+// walked all of a tile's slabs in a serial loop -- latency-bound, 37 us for the 31-way split tiles of the LSTM's
+// recurrent products.)
+template <int BM, int BN, class Epi>
+__global__ void __launch_bounds__(256)
+    fixup(const Epi E, const float* __restrict__ slab, const int M, const int N, const int ktiles, const long G,
+          const int full_rounds, const int rem_tiles, const int ntn) {
+  constexpr int STRIPS = BM * BN / 256;                  // 256-element strips per tile
+  __shared__ float4 part[3][64];
+  const int tr = blockIdx.x / STRIPS, strip = blockIdx.x % STRIPS;
+  const long R = (long)rem_tiles * ktiles;
+  // worker of iteration it: shares are [g*R/G, (g+1)*R/G)  ->  g = ceil((it+1)*G/R) - 1
+  const long it0 = (long)tr * ktiles, it1 = it0 + ktiles - 1;
+  const long ga = ((it0 + 1) * G + R - 1) / R - 1, gb = ((it1 + 1) * G + R - 1) / R - 1;
+  if (gb <= ga) return;                                  // the tile was not split
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int e0 = strip * 256 + lane * 4;                 // tile-local element (row-major [BM][BN]) of this lane's float4
+  const float* S0 = slab + e0;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  // (a worker whose share is empty -- fewer iterations than workers -- wrote no slab: its slot is skipped; shares are
+  //  contiguous, so every non-empty worker between ga and gb lies inside this tile)
+  for (long g = ga + 1 + wave; g <= gb; g += 16) {
+    float4 v[4];
+    bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const long gu = g + 4 * u;
+      ok[u] = gu <= gb && (gu + 1) * R / G > gu * R / G;
+      v[u] = *reinterpret_cast<const float4*>(S0 + (ok[u] ? gu : ga + 1) * (long)(BM * BN));
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+  }
+  if (wave > 0) part[wave - 1][lane] = sum;
+  __syncthreads();
+  if (wave > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) { const float4 p = part[w][lane]; sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w; }
+  const long tile = (long)full_rounds * G + tr;
+  const int m = (int)(tile / ntn) * BM + e0 / BN, n0 = (int)(tile % ntn) * BN + e0 % BN;
+  if (m >= M) return;
+  const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n0 + e < N) *E.ptr(m, n0 + e) += sv[e];
 }
 
 constexpr int NUM_CU = 256;  // MI355X
 
-// split_k_hint > 1 marks a "few tiles, very long K" product whose partial tiles are atomically accumulated by the
-// epilogue (the conv weight gradients): it is cut K-major (see the kernel); everything else is scheduled as
-// data-parallel rounds + one stream-K round.
+// Floats of slab workspace a launch may need: one BM x BN tile per persistent worker (512 x 128x128 = 1024 x 128x64 =
+// 1536 x 64x64 at most).  Callers carve this out of their own workspace (the C ABI's caller-allocates rule).
+constexpr size_t SLAB_FLOATS = (size_t)512 * 128 * 128;
+
+// split_k_hint > 1 marks a "few tiles, very long K" product (the conv weight gradients); with the K-major tuning option
+// it is cut K-major (see the kernel); everything else is scheduled as data-parallel rounds + one stream-K round.
+// `slab`: SLAB_FLOATS floats of scratch for the split tiles of the stream-K round; nullptr selects whole-tile scheduling
+// (slower on tile counts that quantise badly, still deterministic).
 template <int BM, int BN, class AOp, class BOp, class Epi>
 static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N, int K, int split_k_hint,
-                         hipStream_t s) {
+                         hipStream_t s, float* slab = nullptr) {
   if (M <= 0 || N <= 0 || K <= 0) return AVVAD_EINVAL;
   const int ktiles = (K + BK - 1) / BK;
   const long ntiles = (long)cdiv(M, BM) * cdiv(N, BN);
@@ -472,14 +544,17 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   else if (variant == 0) per_cu = BIG ? 2 : (BM * BN >= 128 * 64 ? 3 : 4);
   else if (variant == 1 || !BIG) per_cu = BIG ? 3 : (BM * BN >= 128 * 64 ? 4 : 6);
   else per_cu = 2;
-  long G = (long)NUM_CU * per_cu;
-  const bool no_sk = tn.no_streamk == 1 || tn.no_streamk == 10 + e.mode;   // debugging aid: whole-tile schedule
+  const int cus = (tn.max_cus > 0 && tn.max_cus < NUM_CU) ? tn.max_cus : NUM_CU;   // room for RCCL's kernels at N > 1
+  long G = (long)cus * per_cu;
+  if (G * BM * BN > (long)SLAB_FLOATS) G = (long)(SLAB_FLOATS / ((size_t)BM * BN));
+  const bool no_sk = !slab || tn.no_streamk == 1 || tn.no_streamk == 10 + e.mode;   // whole-tile schedule
   long full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
   int kchunks = 0;
-  // OFF by default (AVVAD_KMAJOR=1 turns it on): it removes most of the wgrad kernel's beyond-L2 fetches, but the
+  // OFF by default (option "kmajor"): it removes most of the wgrad kernel's beyond-L2 fetches, but the
   // kernels are MFMA-bound -- isolated they time the same (+-2 %), and the whole training step measured 0.45 ms
   // (2 %) SLOWER in three A/B/A/B pairs on one device (23.7 vs 23.25 ms), so tile-major stream-K stays the default.
-  if (split_k_hint > 1 && e.mode == 2 && ntiles <= G && tn.kmajor) {
+  // (Cells of one tile are added with float atomics onto an accumulating output: the one non-reproducible schedule left.)
+  if (split_k_hint > 1 && e.mode != 0 && ntiles <= G && tn.kmajor) {
     // r cells per worker (r = 1 or 2): kchunks = floor(r*G / ntiles); cost in K-tile iterations incl. ~8 per atomic flush
     long best = -1;
     for (int r = 1; r <= 2; ++r) {
@@ -497,34 +572,25 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
       if (rem > 0) ++full_rounds;
       rem = 0;
     }
-    if (rem > 0) {
-      if (full_rounds == 0) {           // fewer tiles than workers: >= 4 iterations per worker amortise prologue/epilogue
-        const long cap = iters / 4 > 0 ? iters / 4 : 1;
-        if (G > cap) G = cap;
-      }
-      if (e.mode == 0) {  // split pieces are atomically added: their tiles must start at zero
-        // only the stream-K round's tiles (the last `rem`, in row-major tile order) are added to; the tile rows from the
-        // first of them down cover them -- the data-parallel tiles caught in that band are overwritten by plain stores
-        const long row0 = (full_rounds * G / cdiv(N, BN)) * BM;
-        const long n = (long)(M - row0) * N;
-        if (n > 0)
-          hipLaunchKernelGGL(zero_strided, dim3((int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256)), dim3(256), 0, s,
-                             e.C + row0 * e.ldc, (int)(M - row0), N, e.ldc, e.cs);
-      }
+    if (rem > 0 && full_rounds == 0) {  // fewer tiles than workers: >= 4 iterations per worker amortise prologue/epilogue
+      const long cap = iters / 4 > 0 ? iters / 4 : 1;
+      if (G > cap) G = cap;
     }
   }
   const int fr = (int)full_rounds, rt = (int)rem;
   if constexpr (TALL) {
-    hipLaunchKernelGGL((kernel<BM, BN, false, 512, AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
+    hipLaunchKernelGGL((kernel<BM, BN, false, 512, AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks, slab);
   } else {
     if (variant == 0)
-      hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
+      hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks, slab);
     else if (variant == 1 || !BIG)
-      hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks);
+      hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks, slab);
     else
       hipLaunchKernelGGL((kernel<BM, BN, true, (BIG ? 512 : 256), AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K,
-                         ktiles, fr, rt, kchunks);
+                         ktiles, fr, rt, kchunks, slab);
   }
+  if (rt > 0 && kchunks == 0)
+    hipLaunchKernelGGL((fixup<BM, BN, Epi>), dim3(rt * (BM * BN / 256)), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

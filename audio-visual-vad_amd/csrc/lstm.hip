@@ -6,7 +6,7 @@
 // output steps are zero (so h_{t-1} can simply be read back from y[:, t-1]).
 //
 // Structure per layer: one big input-projection GEMM over all (b,t) rows, then
-// per step a small recurrent GEMM (split-K, float-atomic accumulate onto the
+// per step a small recurrent GEMM (stream-K over the long K, accumulated onto the
 // pre-activations) + one fused gate kernel.  The activated gates overwrite the
 // pre-activations in the workspace and are what backward consumes.
 #include "gemm_api.h"
@@ -177,7 +177,7 @@ __global__ void __launch_bounds__(256)
 }
 
 struct Ws {
-  float *G, *Cs, *bias, *DH, *DC, *Ys;
+  float *G, *Cs, *bias, *DH, *DC, *Ys, *slab;
   size_t total;
 };
 static Ws carve(const avvad_lstm_desc* d, float* base) {
@@ -191,6 +191,7 @@ static Ws carve(const avvad_lstm_desc* d, float* base) {
   w.DH = take(B * H);
   w.DC = take(B * H);
   w.Ys = take(B * T * H);
+  w.slab = take(igemm::SLAB_FLOATS);      // partial tiles of the GEMM engine's stream-K round
   w.total = off;
   return w;
 }
@@ -225,7 +226,7 @@ extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const flo
   hipLaunchKernelGGL(add_bias2, dim3(cdiv(4 * H, 256)), dim3(256), 0, s, b_ih, b_hh, w.bias, 4 * H);
   int rc;
   avvad_gemm_desc gd = gemm_desc(B * T, 4 * H, In, In, In, 4 * H, 0, 1, 0, 1);
-  if ((rc = avvad_gemm_impl(x, w_ih, w.bias, w.G, &gd, s))) return rc;
+  if ((rc = avvad_gemm_impl(x, w_ih, w.bias, w.G, &gd, s, w.slab))) return rc;
   const int split = pick_split(B, 4 * H, H);
   const bool fused_step = (B == 16 || B == 32 || B == 64 || B == 128 || B == 256) && (H % (16 * (256 / B)) == 0) &&
                           !avvad_tune().lstm_no_fused_step;
@@ -236,7 +237,7 @@ extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const flo
     }
     if (t > 0) {
       avvad_gemm_desc rd = gemm_desc(B, 4 * H, H, T * H, H, T * 4 * H, 0, 1, 1, split);
-      if ((rc = avvad_gemm_impl(y + (long)(t - 1) * H, w_hh, nullptr, w.G + (long)t * 4 * H, &rd, s))) return rc;
+      if ((rc = avvad_gemm_impl(y + (long)(t - 1) * H, w_hh, nullptr, w.G + (long)t * 4 * H, &rd, s, w.slab))) return rc;
     }
     hipLaunchKernelGGL(lstm_gates_fwd, dim3(cdiv(B * H, 256)), dim3(256), 0, s, w.G, w.Cs, y, d->lengths, B, T, H, t);
   }
@@ -262,22 +263,22 @@ extern "C" int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const flo
                        H, t);
     if (t > 0) {  // DH = dG_t . W_hh   ([B][4H] x [4H][H])
       avvad_gemm_desc rd = gemm_desc(B, H, 4 * H, T * 4 * H, H, H, 0, 0, 1, split);
-      if ((rc = avvad_gemm_impl(w.G + (long)t * 4 * H, w_hh, nullptr, w.DH, &rd, s))) return rc;
+      if ((rc = avvad_gemm_impl(w.G + (long)t * 4 * H, w_hh, nullptr, w.DH, &rd, s, w.slab))) return rc;
     }
   }
   const int R = B * T;
   if (dx) {
     avvad_gemm_desc g1 = gemm_desc(R, In, 4 * H, 4 * H, In, In, 0, 0, 0, 1);
-    if ((rc = avvad_gemm_impl(w.G, w_ih, nullptr, dx, &g1, s))) return rc;
+    if ((rc = avvad_gemm_impl(w.G, w_ih, nullptr, dx, &g1, s, w.slab))) return rc;
   }
   if (dw_ih) {
     avvad_gemm_desc g2 = gemm_desc(4 * H, In, R, 4 * H, In, In, 1, 0, 1, pick_split(4 * H, In, R));
-    if ((rc = avvad_gemm_impl(w.G, x, nullptr, dw_ih, &g2, s))) return rc;
+    if ((rc = avvad_gemm_impl(w.G, x, nullptr, dw_ih, &g2, s, w.slab))) return rc;
   }
   if (dw_hh) {
     hipLaunchKernelGGL(shift_time, dim3(grid1((long)R * H)), dim3(256), 0, s, y, w.Ys, B, T, H);
     avvad_gemm_desc g3 = gemm_desc(4 * H, H, R, 4 * H, H, H, 1, 0, 1, pick_split(4 * H, H, R));
-    if ((rc = avvad_gemm_impl(w.G, w.Ys, nullptr, dw_hh, &g3, s))) return rc;
+    if ((rc = avvad_gemm_impl(w.G, w.Ys, nullptr, dw_hh, &g3, s, w.slab))) return rc;
   }
   if (db_ih || db_hh)
     hipLaunchKernelGGL(colsum_acc, dim3(cdiv(4 * H, 64)), dim3(256), 0, s, w.G, R, 4 * H, db_ih ? db_ih : db_hh,

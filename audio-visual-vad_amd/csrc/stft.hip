@@ -96,7 +96,7 @@ static bool ok_desc(const avvad_stft_desc* d) {
 extern "C" size_t avvad_stft_workspace(const avvad_stft_desc* d) {
   if (!ok_desc(d)) return 0;
   const size_t ld = ld_of(d);
-  return (align_up((size_t)d->n_fft * ld, 64) + align_up((size_t)d->B * d->T * ld, 64)) * sizeof(float);
+  return (align_up((size_t)d->n_fft * ld, 64) + align_up((size_t)d->B * d->T * ld, 64) + igemm::SLAB_FLOATS) * sizeof(float);
 }
 
 static int stft_impl(const float* wave, float* out, const avvad_stft_desc* d, int mode, const float* mean, const float* stdv,
@@ -130,7 +130,7 @@ static int stft_impl(const float* wave, float* out, const avvad_stft_desc* d, in
   FrameRows a{wave, d->L, M, d->n_fft, d->T, d->hop};
   igemm::ColPlain<4> b{W, ld, ld, d->n_fft, 0};
   igemm::EpiStore e{S, ld, nullptr, 0};
-  int rc = igemm::launch<128, 128>(a, b, e, M, ld, d->n_fft, 1, s);
+  int rc = igemm::launch<128, 128>(a, b, e, M, ld, d->n_fft, 1, s, S + align_up((size_t)M * ld, 64));
   if (rc) return rc;
   if (mode == 2) hipLaunchKernelGGL(to_legacy_view, dim3(grid1((long)d->T * F * 2)), dim3(256), 0, s, S, out, d->T, F, ld);
   else if (mean)

@@ -42,9 +42,10 @@ struct Plan {
   size_t bn_scale, bn_shift, bn_mean, bn_invstd;  // [NCONV][MAXC]
   size_t coef;                                    // [3][MAXC] backward coefficients
   size_t part;                                    // doubles: [STAT_CHUNKS][2][MAXC]
-  size_t c0, p0;
+  size_t c0, p0, am;   // am: arg-max position (0..8, one byte per channel) of every pooled stem element
   size_t blk[8][5];  // c1, a1, c2, cd, out
   size_t G[4], g0, wg;
+  size_t slab;     // igemm::SLAB_FLOATS: partial tiles of the engine's stream-K round
   size_t total;
 };
 
@@ -91,9 +92,11 @@ static void make_plan(const avvad_trunk_desc* d, Plan* p) {
   p->bn_mean = take(NCONV * MAXC); p->bn_invstd = take(NCONV * MAXC);
   p->coef = take(3 * MAXC);
   p->part = take((size_t)STAT_CHUNKS * 2 * MAXC * 2);  // doubles
+  p->slab = take(igemm::SLAB_FLOATS);
   const size_t N = d->N;
   p->c0 = take(N * p->h[1] * p->w[1] * 64);
   p->p0 = take(N * p->h[2] * p->w[2] * 64);
+  p->am = take(N * p->h[2] * p->w[2] * 16);     // 4 bytes (one channel quad) per word
   for (int s = 0; s < 4; ++s)
     for (int b = 0; b < 2; ++b) {
       const size_t n = N * p->h[s + 2] * p->w[s + 2] * widths[s];
@@ -209,9 +212,11 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// stem: p0 = maxpool3x3/2 pad1 ( relu(bn(c0)) )
+// stem: p0 = maxpool3x3/2 pad1 ( relu(bn(c0)) ).  Also records, per pooled element, WHICH window position (dh*3+dw) holds
+// the maximum -- the first one in row-major scan order, torch's rule (max_pool2d updates on a strict '>') -- so that the
+// backward sends the gradient to exactly that element even when flat image regions produce exact ties.
 __global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
-                                  float* __restrict__ p0, int N, int Hc, int Wc, int Hp, int Wp) {
+                                  float* __restrict__ p0, unsigned* __restrict__ am, int N, int Hc, int Wc, int Hp, int Wp) {
   const long total = (long)N * Hp * Wp * 16;  // 64 channels = 16 quads
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i & 15);
@@ -220,6 +225,7 @@ __global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __r
     const int ph = (int)(r % Hp); const int n = (int)(r / Hp);
     const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sh = *reinterpret_cast<const float4*>(shift + q * 4);
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    unsigned idx[4] = {0, 0, 0, 0};
     for (int dh = 0; dh < 3; ++dh) {
       const int h = ph * 2 - 1 + dh;
       if ((unsigned)h >= (unsigned)Hc) continue;
@@ -227,21 +233,22 @@ __global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __r
         const int w = pw * 2 - 1 + dw;
         if ((unsigned)w >= (unsigned)Wc) continue;
         const float4 v = *reinterpret_cast<const float4*>(c0 + ((long)(n * Hc + h) * Wc + w) * 64 + q * 4);
-        m[0] = fmaxf(m[0], fmaxf(bn_affine(v.x, sc.x, sh.x), 0.f));
-        m[1] = fmaxf(m[1], fmaxf(bn_affine(v.y, sc.y, sh.y), 0.f));
-        m[2] = fmaxf(m[2], fmaxf(bn_affine(v.z, sc.z, sh.z), 0.f));
-        m[3] = fmaxf(m[3], fmaxf(bn_affine(v.w, sc.w, sh.w), 0.f));
+        const float y[4] = {fmaxf(bn_affine(v.x, sc.x, sh.x), 0.f), fmaxf(bn_affine(v.y, sc.y, sh.y), 0.f),
+                            fmaxf(bn_affine(v.z, sc.z, sh.z), 0.f), fmaxf(bn_affine(v.w, sc.w, sh.w), 0.f)};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (y[k] > m[k]) { m[k] = y[k]; idx[k] = (unsigned)(dh * 3 + dw); }
       }
     }
     reinterpret_cast<float4*>(p0)[i] = make_float4(m[0], m[1], m[2], m[3]);
+    if (am) am[i] = idx[0] | (idx[1] << 8) | (idx[2] << 16) | (idx[3] << 24);
   }
 }
 
-// stem backward of pool+relu: g0[n,h,w,c] = sum over pooled windows whose max is this element of dp0
-// (the max is recomputed with the identical expression, so equality is exact; zero ties carry no
-// gradient through the ReLU anyway; positive ties go to the first maximum in scan order, like torch).
+// stem backward of pool+relu: g0[n,h,w,c] = sum of dp0 over the pooled windows whose recorded arg-max is this element,
+// masked by the ReLU (an all-zero window's arg-max carries no gradient).
 __global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
-                                   const float* __restrict__ p0, const float* __restrict__ dp0, float* __restrict__ g0,
+                                   const unsigned* __restrict__ am, const float* __restrict__ dp0, float* __restrict__ g0,
                                    int N, int Hc, int Wc, int Hp, int Wp) {
   const long total = (long)N * Hc * Wc * 16;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -251,8 +258,8 @@ __global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __
     const int h = (int)(r % Hc); const int n = (int)(r / Hc);
     const float4 sc = *reinterpret_cast<const float4*>(scale + q * 4), sh = *reinterpret_cast<const float4*>(shift + q * 4);
     const float4 v = reinterpret_cast<const float4*>(c0)[i];
-    const float y[4] = {fmaxf(bn_affine(v.x, sc.x, sh.x), 0.f), fmaxf(bn_affine(v.y, sc.y, sh.y), 0.f),
-                        fmaxf(bn_affine(v.z, sc.z, sh.z), 0.f), fmaxf(bn_affine(v.w, sc.w, sh.w), 0.f)};
+    const bool pos[4] = {bn_affine(v.x, sc.x, sh.x) > 0.f, bn_affine(v.y, sc.y, sh.y) > 0.f, bn_affine(v.z, sc.z, sh.z) > 0.f,
+                         bn_affine(v.w, sc.w, sh.w) > 0.f};
     float g[4] = {0, 0, 0, 0};
     const int ph0 = max(0, h / 2), ph1 = min(Hp - 1, (h + 1) / 2);
     const int pw0 = max(0, w / 2), pw1 = min(Wp - 1, (w + 1) / 2);
@@ -260,29 +267,14 @@ __global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __
       for (int pw = pw0; pw <= pw1; ++pw) {
         // window of (ph,pw) covers rows 2ph-1..2ph+1
         if (h < 2 * ph - 1 || h > 2 * ph + 1 || w < 2 * pw - 1 || w > 2 * pw + 1) continue;
-        const long o = ((long)(n * Hp + ph) * Wp + pw) * 64 + q * 4;
-        const float4 pm = *reinterpret_cast<const float4*>(p0 + o), dp = *reinterpret_cast<const float4*>(dp0 + o);
-        bool hit[4] = {y[0] > 0.f && pm.x == y[0], y[1] > 0.f && pm.y == y[1], y[2] > 0.f && pm.z == y[2],
-                       y[3] > 0.f && pm.w == y[3]};
-        if (hit[0] | hit[1] | hit[2] | hit[3]) {
-          // torch's max_pool2d keeps ONE argmax per window: the first maximum in row-major scan order (its update is a
-          // strict '>').  On an exact positive tie (flat image regions give identical conv outputs) only that element
-          // receives the gradient: drop this one if an EARLIER element of the window reaches the same maximum.
-          for (int hh = max(0, 2 * ph - 1); hh <= h; ++hh) {
-            const int wend = (hh == h) ? w - 1 : min(Wc - 1, 2 * pw + 1);
-            for (int ww = max(0, 2 * pw - 1); ww <= wend; ++ww) {
-              const float4 e = *reinterpret_cast<const float4*>(c0 + ((long)(n * Hc + hh) * Wc + ww) * 64 + q * 4);
-              if (fmaxf(bn_affine(e.x, sc.x, sh.x), 0.f) == pm.x) hit[0] = false;
-              if (fmaxf(bn_affine(e.y, sc.y, sh.y), 0.f) == pm.y) hit[1] = false;
-              if (fmaxf(bn_affine(e.z, sc.z, sh.z), 0.f) == pm.z) hit[2] = false;
-              if (fmaxf(bn_affine(e.w, sc.w, sh.w), 0.f) == pm.w) hit[3] = false;
-            }
-          }
-          if (hit[0]) g[0] += dp.x;
-          if (hit[1]) g[1] += dp.y;
-          if (hit[2]) g[2] += dp.z;
-          if (hit[3]) g[3] += dp.w;
-        }
+        const unsigned me = (unsigned)((h - (2 * ph - 1)) * 3 + (w - (2 * pw - 1)));
+        const long o = ((long)(n * Hp + ph) * Wp + pw) * 16 + q;
+        const unsigned a = am[o];
+        const float4 dp = reinterpret_cast<const float4*>(dp0)[o];
+        if (pos[0] && (a & 255u) == me) g[0] += dp.x;
+        if (pos[1] && ((a >> 8) & 255u) == me) g[1] += dp.y;
+        if (pos[2] && ((a >> 16) & 255u) == me) g[2] += dp.z;
+        if (pos[3] && (a >> 24) == me) g[3] += dp.w;
       }
     reinterpret_cast<float4*>(g0)[i] = make_float4(g[0], g[1], g[2], g[3]);
   }
@@ -314,7 +306,7 @@ static inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4
 
 // ------------------------------------------------------------------ conv launchers
 static inline bool fits_u31(long n) { return n >= 0 && n < (1L << 31); }
-static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s) {
+static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab) {
   const int M = g.N * g.Ho * g.Wo, K = g.KS * g.KS * g.C;
   igemm::EpiStore e{y, g.Co, nullptr, 0};
   if (g.C == 1) {
@@ -327,18 +319,18 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
     }
     igemm::ColPlain<4> b{wf, g.Co, g.Co, K, 0};
     convop::StemFwd a{x, g, M, K};
-    return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s);
+    return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s, slab);
   }
   if (g.C % 32 || g.Co % 4) return AVVAD_EINVAL;
   if (!fits_u31((long)g.N * g.H * g.W * g.C) || !fits_u31((long)K * g.Co)) return AVVAD_EINVAL;   // 32-bit gather offsets
   const int T = g.KS * g.KS;
   convop::ColTapRows b{wf, g.Co, g.Co, K, g.C, T, convop::div_magic(T)};
   convop::Im2colFwd a{x, g, M, convop::tap_div(T, g.KS)};
-  if (g.Co <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s) : igemm::launch<256, 64>(a, b, e, M, g.Co, K, 1, s);
-  return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s);
+  if (g.Co <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s, slab) : igemm::launch<256, 64>(a, b, e, M, g.Co, K, 1, s, slab);
+  return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s, slab);
 }
 // dx (+)= dgrad
-static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s) {
+static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
   const int M = g.N * g.H * g.W, K = g.KS * g.KS * g.Co;
   if (g.Co % 32 || g.C % 4) return AVVAD_EINVAL;
   if (!fits_u31((long)g.N * g.Ho * g.Wo * g.Co) || !fits_u31((long)K * g.C)) return AVVAD_EINVAL;   // 32-bit gather offsets
@@ -366,8 +358,8 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
         convop::EpiS2 e{dx, g.C, nullptr, 1, 1, g.H, g.W, c.Hc, c.Wc, ph, pw, convop::div_magic(c.Hc * c.Wc), convop::div_magic(c.Wc)};
         if ((unsigned long)(Mc + 128) * (unsigned long)(c.Hc * c.Wc) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
         int rc;
-        if (g.C <= 64) rc = igemm::launch<128, 64>(a, b, e, Mc, g.C, ntap * g.Co, 1, s);
-        else rc = igemm::launch<128, 128>(a, b, e, Mc, g.C, ntap * g.Co, 1, s);
+        if (g.C <= 64) rc = igemm::launch<128, 64>(a, b, e, Mc, g.C, ntap * g.Co, 1, s, slab);
+        else rc = igemm::launch<128, 128>(a, b, e, Mc, g.C, ntap * g.Co, 1, s, slab);
         if (rc) return rc;
       }
     return AVVAD_OK;
@@ -376,31 +368,30 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
   const int T = g.KS * g.KS;
   convop::ColTapRows b{wd, g.C, g.C, K, g.Co, T, convop::div_magic(T)};
   convop::Im2colDgrad a{dy, g, M, convop::tap_div(T, g.KS)};
-  if (g.C <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s) : igemm::launch<256, 64>(a, b, e, M, g.C, K, 1, s);
-  return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s);
+  if (g.C <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s, slab) : igemm::launch<256, 64>(a, b, e, M, g.C, K, 1, s, slab);
+  return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s, slab);
 }
-// pk[(kh,kw,c)][co] = wgrad (pk zeroed here; split-K partials are added atomically)
-static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s) {
+// pk[(kh,kw,c)][co] = wgrad (overwritten; tiles split along K are combined by the engine's fix-up kernel, in a fixed order)
+static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s, float* slab) {
   const int M = g.KS * g.KS * g.C, K = g.N * g.Ho * g.Wo;
-  hipLaunchKernelGGL(zero_f32, dim3(ew_grid((long)M * g.Co)), dim3(256), 0, s, pk, (long)M * g.Co);
   igemm::ColPlain<4> b{dy, g.Co, g.Co, K, 0};
   const int ktiles = cdiv(K, igemm::BK);
   if (g.C == 1) {
-    igemm::EpiStore e{pk, g.Co, nullptr, 2};
+    igemm::EpiStore e{pk, g.Co, nullptr, 0};
     convop::StemWgradX a{x, g, M, K};
     int split = 1024; if (split > ktiles) split = ktiles;
-    return igemm::launch<64, 64>(a, b, e, M, g.Co, K, split, s);
+    return igemm::launch<64, 64>(a, b, e, M, g.Co, K, split, s, slab);
   }
   if (g.C % 32) return AVVAD_EINVAL;
-  convop::EpiWgrad e{pk, g.Co, nullptr, 2, 1, g.C, g.KS * g.KS, convop::div_magic(g.KS * g.KS)};
+  convop::EpiWgrad e{pk, g.Co, nullptr, 0, 1, g.C, g.KS * g.KS, convop::div_magic(g.KS * g.KS)};
   if ((unsigned long)(K + igemm::BK) * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
   if (!fits_u31((long)g.N * g.H * g.W * g.C)) return AVVAD_EINVAL;                                              // 32-bit gather offsets
   convop::WgradX a{x, g, M, K, convop::div_magic(g.Ho * g.Wo), convop::div_magic(g.Wo)};
   const bool small = g.Co <= 64;
   const int nb = cdiv(M, 128) * cdiv(g.Co, small ? 64 : 128);
   int split = cdiv(1024, nb); if (split > ktiles) split = ktiles;
-  if (small) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, split, s);
-  return igemm::launch<128, 128>(a, b, e, M, g.Co, K, split, s);
+  if (small) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, split, s, slab);
+  return igemm::launch<128, 128>(a, b, e, M, g.Co, K, split, s, slab);
 }
 
 struct StatCtx { double* part; int nchunk; long rows_per_chunk; };
@@ -475,11 +466,14 @@ extern "C" int avvad_conv2d_pack_weights(const float* w_oihw, float* wf, float* 
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }
-extern "C" int avvad_conv2d_fwd(const float* x, const float* wf, float* y, const avvad_conv_desc* d, avvad_stream_t s) {
+static float* slab_of(void* ws, size_t ws_bytes) { return (ws && ws_bytes >= igemm::SLAB_FLOATS * sizeof(float)) ? (float*)ws : nullptr; }
+extern "C" size_t avvad_engine_workspace(void) { return igemm::SLAB_FLOATS * sizeof(float); }
+extern "C" int avvad_conv2d_fwd(const float* x, const float* wf, float* y, const avvad_conv_desc* d, void* ws, size_t ws_bytes,
+                                avvad_stream_t s) {
   AVVAD_ENTER();
   Geom g;
   if (!x || !wf || !y || !conv_geom(d, &g)) return AVVAD_EINVAL;
-  return conv_fwd(x, wf, y, g, (hipStream_t)s);
+  return conv_fwd(x, wf, y, g, (hipStream_t)s, slab_of(ws, ws_bytes));
 }
 #ifdef AVVAD_PROF
 extern "C" int avvad_debug_prof(unsigned long long* out, int reset) {
@@ -501,18 +495,18 @@ extern "C" int avvad_debug_prof_hw(unsigned long long* out, int n) {
 }
 #endif
 extern "C" int avvad_conv2d_dgrad(const float* dy, const float* wd, float* dx, const avvad_conv_desc* d, int accumulate,
-                                  avvad_stream_t s) {
+                                  void* ws, size_t ws_bytes, avvad_stream_t s) {
   AVVAD_ENTER();
   Geom g;
   if (!dy || !wd || !dx || !conv_geom(d, &g)) return AVVAD_EINVAL;
-  return conv_dgrad(dy, wd, dx, g, accumulate, (hipStream_t)s);
+  return conv_dgrad(dy, wd, dx, g, accumulate, (hipStream_t)s, slab_of(ws, ws_bytes));
 }
-extern "C" int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_packed, const avvad_conv_desc* d,
-                                  avvad_stream_t s) {
+extern "C" int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_packed, const avvad_conv_desc* d, void* ws,
+                                  size_t ws_bytes, avvad_stream_t s) {
   AVVAD_ENTER();
   Geom g;
   if (!x || !dy || !dw_packed || !conv_geom(d, &g)) return AVVAD_EINVAL;
-  return conv_wgrad(x, dy, dw_packed, g, (hipStream_t)s);
+  return conv_wgrad(x, dy, dw_packed, g, (hipStream_t)s, slab_of(ws, ws_bytes));
 }
 
 extern "C" size_t avvad_trunk_workspace(const avvad_trunk_desc* d) {
@@ -520,6 +514,21 @@ extern "C" size_t avvad_trunk_workspace(const avvad_trunk_desc* d) {
   Plan p;
   make_plan(d, &p);
   return p.total * sizeof(float);
+}
+
+// Where the post-ReLU activations a forward run with save_for_backward keeps in its workspace live (test support: the
+// parity tests compare their sign patterns with the oracle's to tell a flipped ReLU unit from an indexing error).
+// index 0: pooled stem output; 1 + 2k: block k's first activation (after bn1 + ReLU); 2 + 2k: block k's output. NHWC.
+extern "C" int avvad_trunk_activation(const avvad_trunk_desc* d, int index, size_t* offset_floats, int* C, int* H, int* W) {
+  if (!d || d->N <= 0 || d->H < 32 || d->W < 32 || index < 0 || index > 16 || !offset_floats || !C || !H || !W) return AVVAD_EINVAL;
+  Plan p;
+  make_plan(d, &p);
+  const int widths[4] = {64, 128, 256, 512};
+  if (index == 0) { *offset_floats = p.p0; *C = 64; *H = p.h[2]; *W = p.w[2]; return AVVAD_OK; }
+  const int k = (index - 1) / 2, st = k / 2;
+  *offset_floats = p.blk[k][(index - 1) % 2 == 0 ? 1 : 4];
+  *C = widths[st]; *H = p.h[st + 2]; *W = p.w[st + 2];
+  return AVVAD_OK;
 }
 
 extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* prm, float* feat, const avvad_trunk_desc* d,
@@ -542,11 +551,13 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
   }
   // stem
   const long N = d->N;
-  if ((rc = conv_fwd(frames, ws + p.wf[0], ws + p.c0, p.geom[0], s))) return rc;
+  if ((rc = conv_fwd(frames, ws + p.wf[0], ws + p.c0, p.geom[0], s, ws + p.slab))) return rc;
   const long M0 = N * p.h[1] * p.w[1];
   if ((rc = bn_prepare(&p, ws, 0, ws + p.c0, M0, prm, d, s))) return rc;
   hipLaunchKernelGGL(stem_bn_relu_pool, dim3(ew_grid(N * p.h[2] * p.w[2] * 16)), dim3(256), 0, s, ws + p.c0,
-                     ws + p.bn_scale, ws + p.bn_shift, ws + p.p0, d->N, p.h[1], p.w[1], p.h[2], p.w[2]);
+                     ws + p.bn_scale, ws + p.bn_shift, ws + p.p0,
+                     d->save_for_backward ? reinterpret_cast<unsigned*>(ws + p.am) : (unsigned*)nullptr, d->N, p.h[1], p.w[1],
+                     p.h[2], p.w[2]);
   // residual stages
   const float* x = ws + p.p0;
   int ci = 1;
@@ -559,15 +570,15 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
       const long M = N * p.h[st + 2] * p.w[st + 2];
       const long nq = M * C / 4;
       const int i1 = ci, i2 = ci + 1, id = ci + 2;
-      if ((rc = conv_fwd(x, ws + p.wf[i1], ws + o[0], p.geom[i1], s))) return rc;
+      if ((rc = conv_fwd(x, ws + p.wf[i1], ws + o[0], p.geom[i1], s, ws + p.slab))) return rc;
       if ((rc = bn_prepare(&p, ws, i1, ws + o[0], M, prm, d, s))) return rc;
       hipLaunchKernelGGL(bn_act, dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[0], ws + p.bn_scale + i1 * MAXC,
                          ws + p.bn_shift + i1 * MAXC, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
                          ws + o[1], nq, C, 1);
-      if ((rc = conv_fwd(ws + o[1], ws + p.wf[i2], ws + o[2], p.geom[i2], s))) return rc;
+      if ((rc = conv_fwd(ws + o[1], ws + p.wf[i2], ws + o[2], p.geom[i2], s, ws + p.slab))) return rc;
       if ((rc = bn_prepare(&p, ws, i2, ws + o[2], M, prm, d, s))) return rc;
       if (ds) {
-        if ((rc = conv_fwd(x, ws + p.wf[id], ws + o[3], p.geom[id], s))) return rc;
+        if ((rc = conv_fwd(x, ws + p.wf[id], ws + o[3], p.geom[id], s, ws + p.slab))) return rc;
         if ((rc = bn_prepare(&p, ws, id, ws + o[3], M, prm, d, s))) return rc;
         hipLaunchKernelGGL(bn_act, dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
                            ws + p.bn_shift + i2 * MAXC, ws + o[3], ws + p.bn_scale + id * MAXC, ws + p.bn_shift + id * MAXC,
@@ -607,7 +618,7 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
                      p.h[5] * p.w[5], 512);
   auto wgrad = [&](int i, const float* xin, const float* dyraw) -> int {
     if (!g->conv_w[i]) return AVVAD_OK;
-    int r = conv_wgrad(xin, dyraw, wg, p.geom[i], s);
+    int r = conv_wgrad(xin, dyraw, wg, p.geom[i], s, ws + p.slab);
     if (r) return r;
     const ConvSpec& c = p.conv[i];
     if (i == 0) hipLaunchKernelGGL(unpack_stem_wgrad, dim3(cdiv(64 * 147, 256)), dim3(256), 0, s, wg, g->conv_w[0]);
@@ -631,23 +642,24 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
         // identity branch through downsample BN + 1x1 conv: d cd in G2, d x in G3
         if ((rc = bn_backward(&p, ws, id, ws + o[3], G0, ws + o[4], G2, nullptr, M, prm, g, d, s))) return rc;
         if ((rc = wgrad(id, x, G2))) return rc;
-        if ((rc = conv_dgrad(G2, ws + p.wd[id], G3, p.geom[id], 0, s))) return rc;
+        if ((rc = conv_dgrad(G2, ws + p.wd[id], G3, p.geom[id], 0, s, ws + p.slab))) return rc;
       } else {
         // identity branch: d x = masked d out (written to G3 by the apply kernel)
         if ((rc = bn_backward(&p, ws, i2, ws + o[2], G0, ws + o[4], G1, G3, M, prm, g, d, s))) return rc;
       }
       if ((rc = wgrad(i2, ws + o[1], G1))) return rc;
-      if ((rc = conv_dgrad(G1, ws + p.wd[i2], G2, p.geom[i2], 0, s))) return rc;  // d a1 in G2
+      if ((rc = conv_dgrad(G1, ws + p.wd[i2], G2, p.geom[i2], 0, s, ws + p.slab))) return rc;  // d a1 in G2
       if ((rc = bn_backward(&p, ws, i1, ws + o[0], G2, ws + o[1], G1, nullptr, M, prm, g, d, s))) return rc;  // d c1 in G1
       if ((rc = wgrad(i1, x, G1))) return rc;
-      if ((rc = conv_dgrad(G1, ws + p.wd[i1], G3, p.geom[i1], 1, s))) return rc;  // d x += ...
+      if ((rc = conv_dgrad(G1, ws + p.wd[i1], G3, p.geom[i1], 1, s, ws + p.slab))) return rc;  // d x += ...
       float* t = G0; G0 = G3; G3 = t;
     }
   // stem: G0 = d p0
   if (g->conv_w[0] || g->bn_w[0] || g->bn_b[0]) {
     float* g0 = ws + p.g0;
     hipLaunchKernelGGL(stem_pool_relu_bwd, dim3(ew_grid(N * p.h[1] * p.w[1] * 16)), dim3(256), 0, s, ws + p.c0,
-                       ws + p.bn_scale, ws + p.bn_shift, ws + p.p0, G0, g0, d->N, p.h[1], p.w[1], p.h[2], p.w[2]);
+                       ws + p.bn_scale, ws + p.bn_shift, reinterpret_cast<const unsigned*>(ws + p.am), G0, g0, d->N, p.h[1], p.w[1],
+                       p.h[2], p.w[2]);
     const long M0 = N * p.h[1] * p.w[1];
     // in place: d c0 overwrites g0
     if ((rc = bn_backward(&p, ws, 0, ws + p.c0, g0, nullptr, g0, nullptr, M0, prm, g, d, s))) return rc;

@@ -905,6 +905,7 @@ struct Plan {
   size_t z, dz, ga, gb, dzt;
   size_t zs[66];    // per-layer pre-ReLU dilation outputs kept for backward (MFMA shape); else 0
   size_t slab;      // weight-gradient partial slabs
+  size_t gslab;     // GEMM engine scratch (weight gradients of shapes / switches that go through igemm)
   size_t total;
 };
 static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
@@ -931,6 +932,7 @@ static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
       const size_t a = (size_t)WG_MAXBLK * WG_SLAB, b2 = (size_t)256 * ((size_t)d->Bn * 33);
       p->slab = take(a > b2 ? a : b2);
     }
+    p->gslab = take(igemm::SLAB_FLOATS);
   } else {
     for (int i = 0; i < p->n; ++i) p->zs[i] = 0;
     const size_t a = take(B * d->R * p->L[0]), b2 = take(B * d->R * p->L[0]);
@@ -946,7 +948,7 @@ static inline bool mfma_shape(const avvad_wavenet_desc* d) { return d->R == 32 &
 
 // dw[co][ci][k] += sum_{b,t} dy[b][co][t] * f(x[b][ci][t + k*dil])  for every tap, on the engine
 static int wgrad_conv1d(const float* dy, const float* x, float* dw, int B, int Cout, int Cin, int Lout, int Lin, int fw,
-                        int dil, int relu_in, hipStream_t s) {
+                        int dil, int relu_in, hipStream_t s, float* slab) {
   const long K = (long)B * Lout;
   if (K > 0x7fffffffL) return AVVAD_EINVAL;
   const int ktiles = cdiv(K, igemm::BK);
@@ -956,8 +958,8 @@ static int wgrad_conv1d(const float* dy, const float* x, float* dw, int B, int C
   // one launch for all taps: column n = ci*fw + k is exactly the [Cout][Cin][fw] weight layout
   igemm::RowSegK a{dy, Lout, (long)Cout * Lout, Cout, (int)K, Lout, 0, 0, 1, 0};
   igemm::RowSegK b{x, Lin, (long)Cin * Lin, Cin * fw, (int)K, Lout, 0, relu_in, fw, dil};
-  igemm::EpiStore e{dw, (long)Cin * fw, nullptr, 2};
-  return igemm::launch<64, 64>(a, b, e, Cout, Cin * fw, (int)K, split, s);
+  igemm::EpiStore e{dw, (long)Cin * fw, nullptr, 1};     // dw += (split tiles combined by the engine's fix-up kernel)
+  return igemm::launch<64, 64>(a, b, e, Cout, Cin * fw, (int)K, split, s, slab);
 }
 
 static void bias_grad(const float* dy, float* db, int B, int C, int L, hipStream_t s) {
@@ -1084,7 +1086,7 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
                        d->use_bias ? prm->bott_b : (const float*)nullptr, dout, DZT, B, R, Bn, Lv, d->P);
   }
   if (!tail_fused) {
-    if (g->bott_w && (rc = wgrad_conv1d(DZT, ws + p.s[p.n], g->bott_w, B, Bn, R, Lv, Lv, 1, 1, 0, s))) return rc;
+    if (g->bott_w && (rc = wgrad_conv1d(DZT, ws + p.s[p.n], g->bott_w, B, Bn, R, Lv, Lv, 1, 1, 0, s, ws + p.gslab))) return rc;
     if (d->use_bias) bias_grad(DZT, g->bott_b, B, Bn, Lv, s);
   }
   if (!tail_mfma)
@@ -1142,12 +1144,12 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
       hipLaunchKernelGGL(wn_block_bwd_dx_mfma, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
     } else {
       // dense (1x1) layer: d W_dense = GA . relu(z)^T ; d b ; dz = (z>0) * W_dense^T GA
-      if (g->dense_w_h[i] && (rc = wgrad_conv1d(GA, Zi, g->dense_w_h[i], B, R, D, Lo, Lo, 1, 1, 1, s))) return rc;
+      if (g->dense_w_h[i] && (rc = wgrad_conv1d(GA, Zi, g->dense_w_h[i], B, R, D, Lo, Lo, 1, 1, 1, s, ws + p.gslab))) return rc;
       if (d->use_bias) bias_grad(GA, g->dense_b_h[i], B, R, Lo, s);
       hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * D * Lo)), dim3(256), 0, s, GA, prm->dense_w_h[i], Zi,
                          (const float*)nullptr, DZ, B, D, R, Lo, Lo, 1, 1, 0, 0);
       // dilated layer: d W_dil = dz . relu(s_i shifted)^T ; d b ; d s_i = (s_i>0) * W_dil^T (*) dz + left-padded GA
-      if (g->dil_w_h[i] && (rc = wgrad_conv1d(DZ, si, g->dil_w_h[i], B, D, R, Lo, Li, fw, dil, 1, s))) return rc;
+      if (g->dil_w_h[i] && (rc = wgrad_conv1d(DZ, si, g->dil_w_h[i], B, D, R, Lo, Li, fw, dil, 1, s, ws + p.gslab))) return rc;
       if (d->use_bias) bias_grad(DZ, g->dil_b_h[i], B, D, Lo, s);
       hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Li)), dim3(256), 0, s, DZ, prm->dil_w_h[i], si, GA,
                          GB, B, R, D, Li, Lo, fw, dil, Li - Lo, Lo);
@@ -1160,7 +1162,7 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
       hipLaunchKernelGGL(narrow_conv1d_grads, dim3(R, B < 32 ? B : 32), dim3(256), 0, s, GA, wave, g->causal_w,
                          d->use_bias ? g->causal_b : (float*)nullptr, B, R, d->qc, p.L[0], d->L, fw);
   } else {
-    if (g->causal_w && (rc = wgrad_conv1d(GA, wave, g->causal_w, B, R, d->qc, p.L[0], d->L, fw, 1, 0, s))) return rc;
+    if (g->causal_w && (rc = wgrad_conv1d(GA, wave, g->causal_w, B, R, d->qc, p.L[0], d->L, fw, 1, 0, s, ws + p.gslab))) return rc;
     if (d->use_bias) bias_grad(GA, g->causal_b, B, R, p.L[0], s);
   }
   if (dwave)

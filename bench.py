@@ -160,13 +160,15 @@ def roofline_probe(torch, n_frames, reps=5):
     """Per-launch duration (HIP events on the launch stream = torch's current stream) of the dominant kernel: the
     fp32-MFMA implicit-GEMM convolution igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,...>, i.e. the forward of
     every trunk conv with Cout >= 128 (15 launches per step).  achieved = algorithmic FLOPs of those launches
-    (2*N*Ho*Wo*Co*KS^2*C each) / their summed duration, everything the launch needs included.  `traffic` is the
+    (2*N*Ho*Wo*Co*KS^2*C each) / their summed duration, everything the launch needs included (the GEMM kernel and,
+    where a shape's tile count leaves a stream-K round, its fix-up kernel).  `traffic` is the
     per-launch HBM-side byte count from the rocprofv3 PMC passes committed under profiles/."""
     from avvad import _lib as L
     lib = L.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     tot_flop, tot_ms, n_launch = 0.0, 0.0, 0
     per = []
+    ews = torch.empty(lib.avvad_engine_workspace() // 4, device="cuda")     # the engine's stream-K scratch (caller-allocated)
     for (c, co, h, w, ks, stride, pad) in trunk_conv_shapes(n_frames):
         if co < 128:
             continue
@@ -175,8 +177,8 @@ def roofline_probe(torch, n_frames, reps=5):
         wf = torch.randn(ks * ks * c, co, device="cuda") * 0.05
         y = torch.empty(n_frames, ho, ho, co, device="cuda")
         d = L.ConvDesc(n_frames, h, w, c, co, ks, stride, pad)
-        L.check(lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), st), "conv fwd")
-        ms = _events(torch, lambda: lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), st), reps)
+        L.check(lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), L.ptr(ews), ews.numel() * 4, st), "conv fwd")
+        ms = _events(torch, lambda: lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), L.ptr(ews), ews.numel() * 4, st), reps)
         flop = 2.0 * n_frames * ho * ho * co * ks * ks * c
         per.append((c, co, h, ks, stride, ms, flop / ms / 1e9))
         tot_flop += flop

@@ -53,8 +53,7 @@ int avvad_get_option(const char* name);
  * Dense GEMM on fp32 MFMA:  C[M,N] (+)= op(A) . op(B) (+ bias[N])
  *   transA=0: A is [M,K] row-major (lda);  transA=1: A is stored [K,M] (lda)
  *   transB=0: B is [K,N] row-major (ldb);  transB=1: B is stored [N,K] (ldb)
- *   accumulate: C += result (needed when split_k > 1: partials are added with
- *   float atomics onto the existing C).
+ *   accumulate: C += result.
  * Replaces: nn.LSTM input / recurrent projections and nn.Linear
  *   (packages/models/Audio_Net.py:30-35,51-59, Video_Net.py:45-51,102-116,
  *    AV_Net.py:53-58,128-140) and their autograd backward.
@@ -64,12 +63,18 @@ typedef struct {
   int lda, ldb, ldc;
   int transA, transB;
   int accumulate;
-  int split_k; /* >= 1 */
+  int split_k; /* >= 1: hint that K is long and the tiles few (needs accumulate) */
   int relu_a;  /* apply max(.,0) to A elements on load */
   int relu_b;
 } avvad_gemm_desc;
+/* Scratch of the GEMM engine, bytes (a constant: one tile per persistent worker).  Tiles whose K range is cut between
+ * workers (the engine's stream-K round) leave their partial sums there and a fix-up kernel adds them in a fixed
+ * order: results are bit-reproducible run to run, there are no float atomics.  Every entry point that runs a single
+ * GEMM / convolution takes (ws, ws_bytes); ws == NULL (or too small) selects whole-tile scheduling -- same results up
+ * to summation order, slower where the tile count quantises badly against the 256 CUs. */
+size_t avvad_engine_workspace(void);
 int avvad_gemm_f32(const float* A, const float* B, const float* bias, float* C,
-                   const avvad_gemm_desc* d, avvad_stream_t s);
+                   const avvad_gemm_desc* d, void* ws, size_t ws_bytes, avvad_stream_t s);
 
 /* ------------------------------------------------------------------------
  * WaveNet-style encoder (valid dilated Conv1d stack)
@@ -173,20 +178,25 @@ typedef struct {
  * per launch for the roofline).  x [N][H][W][C] NHWC, y [N][Ho][Wo][Co]; square kernel KS, stride 1|2.
  * Weights are packed once from OIHW: wf [(kh,kw,c)][co] (forward) and wd [(kh,kw,co)][c] (dgrad; may be
  * NULL).  C must be 1 (stem, forward/wgrad only) or a multiple of 32; Co a multiple of 4.
- * wgrad writes the packed layout [(kh,kw,c)][co] (overwritten).  Replaces nn.Conv2d inside
+ * wgrad writes the packed layout [(kh,kw,c)][co] (overwritten).  ws: avvad_engine_workspace() bytes.  Replaces nn.Conv2d inside
  * torchvision's resnet18 (packages/models/Video_Net.py:35-37). */
 typedef struct {
   int N, H, W, C, Co, KS, stride, pad;
 } avvad_conv_desc;
 int avvad_conv2d_pack_weights(const float* w_oihw, float* wf, float* wd, const avvad_conv_desc* d,
                               avvad_stream_t s);
-int avvad_conv2d_fwd(const float* x, const float* wf, float* y, const avvad_conv_desc* d, avvad_stream_t s);
+int avvad_conv2d_fwd(const float* x, const float* wf, float* y, const avvad_conv_desc* d, void* ws,
+                     size_t ws_bytes, avvad_stream_t s);
 int avvad_conv2d_dgrad(const float* dy, const float* wd, float* dx, const avvad_conv_desc* d,
-                       int accumulate, avvad_stream_t s);
-int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_packed, const avvad_conv_desc* d,
-                       avvad_stream_t s);
+                       int accumulate, void* ws, size_t ws_bytes, avvad_stream_t s);
+int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_packed, const avvad_conv_desc* d, void* ws,
+                       size_t ws_bytes, avvad_stream_t s);
 
 size_t avvad_trunk_workspace(const avvad_trunk_desc* d);
+/* Test support: offset (floats), channels and spatial size of the post-ReLU activation `index` that a forward run with
+ * save_for_backward keeps in its workspace, NHWC.  index 0: pooled stem output; 1 + 2k: block k's first activation
+ * (bn1 + ReLU); 2 + 2k: block k's output (k = 0..7).  The parity tests compare sign patterns with the oracle's. */
+int avvad_trunk_activation(const avvad_trunk_desc* d, int index, size_t* offset_floats, int* C, int* H, int* W);
 int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* p, float* feat /* [N][512] */,
                     const avvad_trunk_desc* d, void* ws, size_t ws_bytes, avvad_stream_t s);
 int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* p, const float* dfeat,

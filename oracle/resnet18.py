@@ -144,6 +144,7 @@ def trunk_forward(sd, x, training=False, prefix="features.", return_intermediate
             s = stride if bi == 0 else 1
             idn = y
             o = F.relu(_bn(F.conv2d(y, sd[p + ".conv1.weight"], None, s, 1), sd, p + ".bn1", training))
+            inter["%d.%d.a1" % (4 + li, bi)] = o
             o = _bn(F.conv2d(o, sd[p + ".conv2.weight"], None, 1, 1), sd, p + ".bn2", training)
             if s != 1 or cin != c:
                 idn = _bn(F.conv2d(y, sd[p + ".downsample.0.weight"], None, s, 0), sd,

@@ -64,6 +64,43 @@ def _report_grad(name, got, ref, scale=1.0, rel_bound=2e-3):
     assert err.max() <= tol or rel <= rel_bound, msg
 
 
+def _relu_flips(out_gpu, ref_inter):
+    """ReLU units of the trunk whose on/off decision differs between the GPU forward behind ``out_gpu`` and the oracle's
+    intermediates: a pre-activation within ~1e-7 of zero can land on either side under two equally valid fp32
+    summation orders (MFMA's ordered fmaf chain vs the CPU library's vectorised partial sums).  Every forward value still
+    agrees to 1e-6, but the flipped unit's gradient path is switched on in one run and off in the other, which moves every
+    upstream gradient by a finite amount.  Returns (flipped units, total units)."""
+    from avvad import ops
+    flips = units = 0
+    for k, t in ops.trunk_saved_activations(out_gpu).items():
+        r = ref_inter[k]
+        assert tuple(t.shape) == tuple(r.shape), (k, t.shape, r.shape)
+        flips += int(((t.cpu() > 0) != (r > 0)).sum())
+        units += r.numel()
+    msg = "ReLU decisions that differ from the oracle: %d of %d" % (flips, units)
+    print(msg)
+    with open(os.path.join(OUT, "parity.log"), "a") as f:
+        f.write(msg + "\n")
+    # an indexing error flips a sizeable fraction of a layer; rounding flips are single units (observed: ~1 per 9 M)
+    assert flips <= 2 + units // 1000000, msg
+    return flips, units
+
+
+def _oracle_trunk_intermediates(state, video, training):
+    """post-ReLU activations of the oracle trunk on video (B,T,H,W) with the ``features.*`` entries of ``state``."""
+    from oracle import resnet18
+    sd = {k: v.detach().clone() for k, v in state.items() if k.startswith("features.")}
+    B, Tn, H, W = video.shape
+    with torch.no_grad():
+        _, inter = resnet18.trunk_forward(sd, video.reshape(B * Tn, 1, H, W).repeat(1, 3, 1, 1), training, return_intermediates=True)
+    return inter
+
+
+def _grad_bound(flips, strict, relaxed=1e-2):
+    """Relative-L2 escape of _report_grad: the strict bound unless a ReLU flip has been PROVEN for this run."""
+    return strict if flips == 0 else relaxed
+
+
 # ------------------------------------------------------------------------------------------ GEMM engine
 @pytest.mark.parametrize("M,N,K,tA,tB", [(128, 128, 64, 0, 1), (100, 70, 513, 0, 1), (64, 4096, 1024, 0, 1),
                                           (37, 130, 96, 0, 0), (130, 64, 40, 1, 0), (4096, 513, 48, 1, 0),
@@ -83,6 +120,36 @@ def test_gemm_variants(M, N, K, tA, tB):
     c1 = c0.clone()
     ops.gemm(a, b, c1, M, N, K, A.shape[1], B.shape[1], N, bool(tA), bool(tB), accumulate=True, split_k=4)
     _report("gemm %dx%dx%d split-k accumulate" % (M, N, K), c1, ref + c0.cpu().numpy(), 1e-5 * np.sqrt(K) * 4)
+
+
+@pytest.mark.parametrize("M,N,K", [(82944, 128, 64), (36992, 64, 576), (25600, 256, 2304), (9216, 512, 300), (1156 * 128 + 5, 128, 96),
+                                   (700, 4096, 40), (64, 1024, 4096)])
+def test_engine_streamk_fixup_equals_whole_tile(M, N, K):
+    """The engine's production schedule (data-parallel rounds + one stream-K round whose split tiles are combined by the
+    fix-up kernel) against its whole-tile schedule on the same operands: several full rounds plus a remainder, K so
+    short that most workers of the stream-K round get an EMPTY share (1x1 convolutions: that case once read slabs nobody
+    had written), fewer tiles than workers, ragged edges.  Also: two runs are bit-identical (no float atomics)."""
+    import ctypes as Ct
+    from avvad import _lib as L, ops
+    rng = np.random.RandomState(M % 1000 + K)
+    A = T(rng.normal(size=(M, K)).astype(np.float32)).to(DEV)
+    B = T(rng.normal(size=(K, N)).astype(np.float32)).to(DEV)
+    bias = T(rng.normal(size=(N,)).astype(np.float32)).to(DEV)
+    lib = L.lib()
+    st = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.GemmDesc(M, N, K, K, N, N, 0, 0, 0, 1, 0, 0)
+    ews = ops.engine_ws(DEV)
+    outs = []
+    for ws in (None, ews, ews):
+        Cc = torch.full((M, N), 7.0, device=DEV)
+        L.check(lib.avvad_gemm_f32(L.ptr(A), L.ptr(B), L.ptr(bias), L.ptr(Cc), Ct.byref(d), L.ptr(ws), 0 if ws is None else ws.numel() * 4, st), "gemm")
+        outs.append(Cc)
+    assert torch.equal(outs[1], outs[2]), "stream-K + fix-up is not reproducible"
+    _report("engine %dx%dx%d stream-K vs whole-tile" % (M, N, K), outs[1], outs[0], 2e-5 * np.sqrt(K), 1e-5)
+    acc = torch.full((M, N), 0.5, device=DEV)
+    d2 = L.GemmDesc(M, N, K, K, N, N, 0, 0, 1, 4, 0, 0)
+    L.check(lib.avvad_gemm_f32(L.ptr(A), L.ptr(B), None, L.ptr(acc), Ct.byref(d2), L.ptr(ews), ews.numel() * 4, st), "gemm acc")
+    _report("engine %dx%dx%d accumulate" % (M, N, K), acc, outs[0] - bias + 0.5, 2e-5 * np.sqrt(K), 1e-5)
 
 
 # ------------------------------------------------------------------------------------------ WaveNet encoder
@@ -220,16 +287,27 @@ def test_conv2d_fwd_dgrad_wgrad(N, H, W, C, Co, KS, stride, pad):
     wdg = torch.empty(KS * KS * C * Co, device=DEV)
     L.check(lib.avvad_conv2d_pack_weights(L.ptr(wd_), L.ptr(wf), L.ptr(wdg), Ct.byref(d), st), "pack")
     yd = torch.empty(N, y.shape[2], y.shape[3], Co, device=DEV)
-    L.check(lib.avvad_conv2d_fwd(L.ptr(xd), L.ptr(wf), L.ptr(yd), Ct.byref(d), st), "fwd")
+    from avvad import ops
+    ews = ops.engine_ws(DEV)
+    wsz = ews.numel() * 4
+    L.check(lib.avvad_conv2d_fwd(L.ptr(xd), L.ptr(wf), L.ptr(yd), Ct.byref(d), L.ptr(ews), wsz, st), "fwd")
     tag = "conv %dx%dx%dx%d->%d k%d s%d" % (N, H, W, C, Co, KS, stride)
     _report(tag + " fwd", yd.permute(0, 3, 1, 2), y, 2e-5, 1e-5)
     gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
     if C > 1 and Co % 32 == 0:      # dgrad contracts over Co in 32-deep K tiles
         dx = torch.empty_like(xd)
-        L.check(lib.avvad_conv2d_dgrad(L.ptr(gyd), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 0, st), "dgrad")
+        L.check(lib.avvad_conv2d_dgrad(L.ptr(gyd), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 0, L.ptr(ews), wsz, st), "dgrad")
         _report(tag + " dgrad", dx.permute(0, 3, 1, 2), x.grad, 2e-5, 1e-5)
     dw = torch.empty(KS * KS * C, Co, device=DEV)
-    L.check(lib.avvad_conv2d_wgrad(L.ptr(xd), L.ptr(gyd), L.ptr(dw), Ct.byref(d), st), "wgrad")
+    L.check(lib.avvad_conv2d_wgrad(L.ptr(xd), L.ptr(gyd), L.ptr(dw), Ct.byref(d), L.ptr(ews), wsz, st), "wgrad")
+    # bit-reproducible: tiles cut along K are combined by the fix-up kernel in a fixed order (no float atomics), and the
+    # whole-tile schedule (no workspace) agrees with it up to the summation order
+    dw2 = torch.empty_like(dw)
+    L.check(lib.avvad_conv2d_wgrad(L.ptr(xd), L.ptr(gyd), L.ptr(dw2), Ct.byref(d), L.ptr(ews), wsz, st), "wgrad again")
+    assert torch.equal(dw, dw2), "wgrad is not reproducible run to run"
+    y2 = torch.empty_like(yd)
+    L.check(lib.avvad_conv2d_fwd(L.ptr(xd), L.ptr(wf), L.ptr(y2), Ct.byref(d), None, 0, st), "fwd, whole-tile schedule")
+    _report(tag + " fwd whole-tile vs stream-K", y2, yd, 2e-5, 1e-5)
     ref_dw = w.grad.permute(2, 3, 1, 0).reshape(KS * KS * C, Co)
     # (stem: the contraction runs over every output pixel of every frame; as ONE fp32 chain -- the whole-tile debug
     #  schedule -- it drifts to 2.5e-4 on sums of magnitude 170, split-K partial sums stay under 1e-4)
@@ -273,13 +351,13 @@ def test_video_net_golden_eval_and_train():
 def test_trunk_backward_vs_oracle(training, streamk, lib_options):
     """gradients of a random projection of the features w.r.t. every trunk parameter.
 
-    streamk=False runs the engine with whole-tile scheduling (AVVAD_NO_STREAMK=all): bit-reproducible, and held to
-    the strict bounds.  streamk=True is the production schedule: the pieces of a split tile are added with float
-    atomics in arrival order, i.e. a different (equally valid) fp32 summation order from run to run (~1e-6 in the
-    forward; train-mode BatchNorm over this 6-frame batch amplifies it to ~1e-5).  ONE ReLU decision that lands on the
-    other side of zero then moves every upstream gradient by ~3e-3 relative L2 (measured: sign pattern of the last
-    block's output differs in 1 of 27648 entries in ~60 % of train-mode runs, and about once in 20 eval-mode runs), so
-    that pass gets the flip-tolerant relative bound.  An indexing bug gives O(1) relative error under either."""
+    streamk=False runs the engine with whole-tile scheduling (option no_streamk), streamk=True the production schedule
+    (data-parallel rounds + a stream-K round whose split tiles are combined by the fix-up kernel in a fixed order).  Both
+    are bit-reproducible -- round 1's float-atomic stream-K was not -- and both are held to the strict bounds.  The one
+    legitimate way to miss them is a ReLU unit whose pre-activation sits within rounding of zero and lands on the other
+    side than in the oracle (different but equally valid fp32 summation orders): that moves every upstream gradient by
+    ~3e-3 relative L2 while the forward agrees to 1e-6.  The test therefore COUNTS such units from the saved activations
+    (_relu_flips) and relaxes the bound only when one is found; an indexing bug flips a whole layer's worth and fails."""
     from oracle import resnet18
     from avvad import nn as avnn
     from packages.models.Video_Net import DeepVAD_video
@@ -290,15 +368,18 @@ def test_trunk_backward_vs_oracle(training, streamk, lib_options):
     G = stategen.rand(22, N, 512)
     sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
           for k, v in sd0.items() if k.startswith("features.")}
-    ref = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), training)
+    ref, inter = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), training, return_intermediates=True)
     (ref * G).sum().backward()
     m = DeepVAD_video(2, 16, 1)
     m.load_state_dict(sd0)
     m = m.to(DEV).train(training)
     f = avnn.trunk_forward(m.features, x.to(DEV), training)
     _report("trunk fwd (training=%s, streamk=%s)" % (training, streamk), f, ref, 1e-4, 1e-5)
+    flips, _ = _relu_flips(f, inter)
     (f * G.to(DEV)).sum().backward()
-    rel = 1e-2 if streamk else (5e-3 if training else 2e-3)
+    # both schedules are deterministic now (no float atomics): both are held to the strict bounds, which open up only when
+    # a flipped ReLU unit has been found in THIS run's activations
+    rel = _grad_bound(flips, 2e-3 if not training else 5e-3)
     for k, p in m.features.named_parameters():
         _report_grad("trunk d/d%s" % k, p.grad, sd["features." + k].grad, 2.0, rel)
 
@@ -347,11 +428,13 @@ def test_av_net_mcb_fusion_vs_oracle():
         y = mg(ag, v.to(DEV), lens)
         tag = "AV+MCB %s" % ("train" if training else "eval")
         _report(tag + " logits", y, ref, 1e-4)
+        flips, _ = _relu_flips(y, _oracle_trunk_intermediates(m.state_dict(), v, training))
         loss = batch_binary_cross_entropy(y, tgt.to(DEV), lens, 1e-8)
         loss.backward()
-        _report_grad(tag + " d/d audio", ag.grad, ar.grad, 2.0, 1e-2)
+        rel = _grad_bound(flips, 5e-3 if training else 2e-3)
+        _report_grad(tag + " d/d audio", ag.grad, ar.grad, 2.0, rel)
         for k in ("mcb_bn.weight", "mcb_bn.bias", "lstm_merged.weight_ih_l0", "features.7.1.conv2.weight", "features.0.weight"):
-            _report_grad(tag + " d/d" + k, dict(mg.named_parameters())[k].grad, sd[k].grad, 2.0, 1e-2)
+            _report_grad(tag + " d/d" + k, dict(mg.named_parameters())[k].grad, sd[k].grad, 2.0, rel)
         if training:
             _report(tag + " running_var", mg.mcb_bn.running_var, sd["mcb_bn.running_var"], 1e-6, 1e-4)
             assert int(mg.mcb_bn.num_batches_tracked) == 1
@@ -375,6 +458,7 @@ def test_av_wavenet_end_to_end_vs_oracle():
     video = torch.randn(B, Tn, 67, 67)
     tgt = (torch.rand(B, Tn, 1) > 0.5).float()
     lens = [4, 2, 3]
+    sd0 = {k: v.detach().clone() for k, v in m.state_dict().items()}
     sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.detach().clone())
           for k, v in m.state_dict().items()}
     ref = models.av_net(sd, wave, video, lens, 2, training=True, wavenet_cfg=wcfg)
@@ -383,6 +467,7 @@ def test_av_wavenet_end_to_end_vs_oracle():
     m = m.to(DEV).train()
     y = m(wave.to(DEV), video.to(DEV), torch.LongTensor(lens))
     _report("AV+WaveNet logits (train)", y, ref, 1e-4)
+    flips, _ = _relu_flips(y, _oracle_trunk_intermediates(sd0, video, True))
     loss = batch_binary_cross_entropy(y, tgt.to(DEV), lens, 1e-8)
     _report("AV+WaveNet loss", loss, ref_loss, 1e-4)
     loss.backward()
@@ -390,7 +475,8 @@ def test_av_wavenet_end_to_end_vs_oracle():
         if p.grad is None:
             assert k.startswith("bn."), k          # the unused BatchNorm1d of the reference
             continue
-        _report_grad("AV+WaveNet d/d" + k, p.grad, sd[k].grad, 2.0, 1e-2)   # train-mode BN on 12 frames: see trunk test
+        # train-mode BatchNorm over 12 frames amplifies rounding differences; the bound relaxes only on a proven ReLU flip
+        _report_grad("AV+WaveNet d/d" + k, p.grad, sd[k].grad, 2.0, _grad_bound(flips, 5e-3))
 
 
 # ------------------------------------------------------------------------------------------ entry points
@@ -527,7 +613,7 @@ def test_count_sketch_and_compact_bilinear_pooling_modules():
     _report_grad("CompactBilinearPooling d/dx", ag.grad, ar.grad)
     _report_grad("CompactBilinearPooling d/dy", vg.grad, vr.grad)
     sq = CompactBilinearPooling(513, 513, 1024, h1, s1, T(rng.randint(0, 1024, 513)), s1.clone()).to(DEV)
-    _report("CompactBilinearPooling(x) == (x, x)", sq(ag.detach()), sq(ag.detach(), ag.detach()), 0.0)
+    _report("CompactBilinearPooling(x) == (x, x)", sq(ag.detach()), sq(ag.detach(), ag.detach()), 1e-5, 1e-6)   # LDS-atomic bucket order
 
 
 def test_bce_2classes_vs_reference():
@@ -586,16 +672,18 @@ def test_stem_maxpool_ties_follow_torch():
     G = stategen.rand(32, N, 512)
     sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
           for k, v in sd0.items() if k.startswith("features.")}
-    ref = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), False)
+    ref, inter = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), False, return_intermediates=True)
     (ref * G).sum().backward()
     m = DeepVAD_video(2, 16, 1)
     m.load_state_dict(sd0)
     m = m.to(DEV).eval()
     f = avnn.trunk_forward(m.features, x.to(DEV), False)
     _report("trunk fwd with flat regions", f, ref, 1e-4, 1e-5)
+    flips, _ = _relu_flips(f, inter)
     (f * G.to(DEV)).sum().backward()
     for k in ("0.weight", "1.weight", "1.bias"):
-        _report_grad("tie-breaking: trunk d/d%s" % k, dict(m.features.named_parameters())[k].grad, sd["features." + k].grad, 2.0, 2e-3)
+        _report_grad("tie-breaking: trunk d/d%s" % k, dict(m.features.named_parameters())[k].grad, sd["features." + k].grad, 2.0,
+                     _grad_bound(flips, 2e-3))
 
 
 # ------------------------------------------------------------------------------------------ C1: evaluate_audio_net plumbing, K19
@@ -744,22 +832,24 @@ def test_full_size_c3_trunk_train_mode_backward(lib_options):
     x = stategen.rand(41, N, 67, 67)
     G = stategen.rand(42, N, 512)
     f = avnn.trunk_forward(m.features, x.to(DEV), True)
-    (f * G.to(DEV)).sum().backward()
-    torch.cuda.synchronize()
     assert f.shape == (N, 512) and torch.isfinite(f).all()
-    for k, p in m.features.named_parameters():
-        assert p.grad is not None and torch.isfinite(p.grad).all(), k
     sd = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
           for k, v in sd0.items() if k.startswith("features.")}
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
-    ref = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), True)
+    ref, inter = resnet18.trunk_forward(sd, x[:, None].repeat(1, 3, 1, 1), True, return_intermediates=True)
     (ref * G).sum().backward()
     _report("C3 train-mode trunk fwd N=512", f, ref, 1e-4, 1e-5)
+    flips, _ = _relu_flips(f, inter)              # (before backward: it frees the saved activations)
+    (f * G.to(DEV)).sum().backward()
+    torch.cuda.synchronize()
+    for k, p in m.features.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
     new = m.state_dict()
     for k in ("features.1.running_mean", "features.1.running_var", "features.7.1.bn2.running_mean", "features.7.1.bn2.running_var"):
         _report("C3 running stat " + k, new[k], sd[k], 1e-5, 1e-5)
     for k in ("0.weight", "1.weight", "4.0.conv1.weight", "5.0.downsample.0.weight", "6.1.bn2.bias", "7.1.conv2.weight"):
-        _report_grad("C3 N=512 trunk d/d%s" % k, dict(m.features.named_parameters())[k].grad, sd["features." + k].grad, 2.0, 5e-3)
+        _report_grad("C3 N=512 trunk d/d%s" % k, dict(m.features.named_parameters())[k].grad, sd["features." + k].grad, 2.0,
+                     _grad_bound(flips, 2e-3))
     # (c) 6-frame slice alone, eval-mode BN, whole-tile schedule, strict bounds
     lib_options("no_streamk", 1)
     m2 = DeepVAD_video(2, 16, 1)
@@ -768,13 +858,14 @@ def test_full_size_c3_trunk_train_mode_backward(lib_options):
     sl = x[100:106]
     sd2 = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone())
            for k, v in sd0.items() if k.startswith("features.")}
-    r2 = resnet18.trunk_forward(sd2, sl[:, None].repeat(1, 3, 1, 1), False)
+    r2, inter2 = resnet18.trunk_forward(sd2, sl[:, None].repeat(1, 3, 1, 1), False, return_intermediates=True)
     (r2 * G[100:106]).sum().backward()
     f2 = avnn.trunk_forward(m2.features, sl.to(DEV), False)
     _report("C3 6-frame slice eval fwd", f2, r2, 1e-4, 1e-5)
+    flips2, _ = _relu_flips(f2, inter2)
     (f2 * G[100:106].to(DEV)).sum().backward()
     for k, p in m2.features.named_parameters():
-        _report_grad("C3 slice d/d%s" % k, p.grad, sd2["features." + k].grad, 2.0, 2e-3)
+        _report_grad("C3 slice d/d%s" % k, p.grad, sd2["features." + k].grad, 2.0, _grad_bound(flips2, 2e-3))
 
 
 def test_full_size_c3_trunk_batch_split_and_scale():

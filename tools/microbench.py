@@ -39,9 +39,10 @@ def conv_case(n, c, co, h, ks, stride, pad, what='fwd'):
     wd = torch.randn(ks * ks * co, c, device='cuda') * 0.05
     y = torch.randn(n, ho, ho, co, device='cuda'); dx = torch.empty_like(x); dw = torch.empty(ks * ks * c, co, device='cuda')
     d = L.ConvDesc(n, h, h, c, co, ks, stride, pad)
-    fns = {'fwd': lambda: lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), st),
-           'dgrad': lambda: lib.avvad_conv2d_dgrad(L.ptr(y), L.ptr(wd), L.ptr(dx), C.byref(d), 0, st),
-           'wgrad': lambda: lib.avvad_conv2d_wgrad(L.ptr(x), L.ptr(y), L.ptr(dw), C.byref(d), st)}
+    ews = torch.empty(lib.avvad_engine_workspace() // 4, device='cuda')
+    fns = {'fwd': lambda: lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), L.ptr(ews), ews.numel() * 4, st),
+           'dgrad': lambda: lib.avvad_conv2d_dgrad(L.ptr(y), L.ptr(wd), L.ptr(dx), C.byref(d), 0, L.ptr(ews), ews.numel() * 4, st),
+           'wgrad': lambda: lib.avvad_conv2d_wgrad(L.ptr(x), L.ptr(y), L.ptr(dw), C.byref(d), L.ptr(ews), ews.numel() * 4, st)}
     ms = timeit(fns[what])
     fl = 2.0 * n * ho * ho * co * ks * ks * c
     print("conv %-5s n=%5d %3d->%3d @%2d k%d s%d : %8.3f ms  %6.1f TFLOP/s" % (what, n, c, co, h, ks, stride, ms, fl / ms / 1e9), flush=True)
