@@ -20,7 +20,7 @@ const OptName kOpts[] = {
     {"no_tall", "AVVAD_NO_TALL", &AvvadTune::no_tall},
     {"wn_no_fused_tail", "AVVAD_WN_NO_FUSED_TAIL", &AvvadTune::wn_no_fused_tail},
     {"wn_no_fused_wgrad", "AVVAD_WN_NO_FUSED_WGRAD", &AvvadTune::wn_no_fused_wgrad},
-    {"wn_no_group", "AVVAD_WN_NO_GROUP", &AvvadTune::wn_no_group},
+    {"wn_bwd_t", "AVVAD_WN_BWD_T", &AvvadTune::wn_bwd_t},
     {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
 };
 int parse_opt(const char* name, const char* v) {

@@ -240,7 +240,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bzl[mfma32_row(r, lh)];
 #pragma unroll
-    for (int s = 0; s < 32; ++s) acc = mfma32(wd[s], fmaxf(x[s], 0.f), acc);
+    for (int s = 0; s < 32; ++s) acc = mfma32(wd[s], relu1(x[s]), acc);
     if (MODE >= 1) {
       float* zp = z_out + (long)b * 32 * Lo + t;
 #pragma unroll
@@ -252,7 +252,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc2[r] = bsl[mfma32_row(r, lh)] + rv[r];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc2 = mfma32(we[r], fmaxf(acc[r], 0.f), acc2);
+      for (int r = 0; r < 16; ++r) acc2 = mfma32(we[r], relu1(acc[r]), acc2);
       float* op = s_out + (long)b * 32 * Lo + t;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
@@ -261,6 +261,13 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+
+// (Round 2 tried two other shapes of this kernel -- tools/lab/mem_lab.py holds the measurements: a 3-waves-per-SIMD form
+//  with the weight fragments read from LDS and no cross-tile prefetch, and one with wave-uniform scalar/buffer addressing
+//  (the flat form spends ~1900 VALU cycles per tile on 64-bit per-lane address arithmetic, and on this chip VALU time adds
+//  to fp32-MFMA time: the matrix instruction runs on the vector lanes).  Both timed within 3 % of this kernel at the bench
+//  and C2 shapes: its ~36 us per bench-shape layer are the SUM of the access pattern's streaming time (20 us alone) and the
+//  matrix time (15 us alone), and neither occupancy nor fewer VALU instructions made the two overlap.)
 
 // ------------------------------------------------------------------ fused MFMA backward of a residual block (R = D = 32, fw = 2)
 // (A)  dz[d][t] = (z[d][t] > 0) * sum_r W_dense[r][d] * dS[r][t]            -- 16 MFMAs per 32-sample tile
@@ -413,7 +420,7 @@ __global__ void __launch_bounds__(256)
         for (int k = 0; k < 16; ++k) acc = mfma32(x[k], w[n][k], acc);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
-          if (t0 + mfma32_row(r, lh) < e) sum[n] += fmaxf(acc[r] + bias[n], 0.f);
+          if (t0 + mfma32_row(r, lh) < e) sum[n] += relu1(acc[r] + bias[n]);
       }
     }
     const float inv = 1.f / (float)(e - a);
@@ -681,7 +688,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const float x = ok ? v[q] : 0.f;
-      T[(2 * q + lh) * 33 + li] = relu ? fmaxf(x, 0.f) : x;
+      T[(2 * q + lh) * 33 + li] = relu ? relu1(x) : x;
     }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -812,7 +819,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 16; ++q) g[q] = ok ? gn[q] : 0.f;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) x[c] = ok ? fmaxf(xn[c], 0.f) : 0.f;      // relu(s tap lh), zero outside the tile
+    for (int c = 0; c < 32; ++c) x[c] = ok ? relu1(xn[c]) : 0.f;      // relu(s tap lh), zero outside the tile
     issue(tl + nwaves);
     // pin the 48 loads HERE: left alone hipcc sinks each one down to its consumer (load, wait, mfma, load, wait, ...),
     // 32 serial memory round trips per tile -- the kernel ran 2.5x slower than the two it replaces
@@ -858,7 +865,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 16; ++q) T[(2 * q + lh) * 33 + li] = g[q];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile[wave][1][mfma32_row(r, lh) * 33 + li] = ok ? fmaxf(z[r], 0.f) : 0.f;
+    for (int r = 0; r < 16; ++r) tile[wave][1][mfma32_row(r, lh) * 33 + li] = ok ? relu1(z[r]) : 0.f;
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) { f0[q] = T[li * 33 + 2 * q + lh]; bs_ds += f0[q]; }
@@ -867,6 +874,153 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc2 = mfma32(f0[q], f1[q], acc2);
     __builtin_amdgcn_wave_barrier();
+  }
+
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = mfma32_row(r, lh);
+    atomicAdd(&red[row * 32 + li], acc0[r]);
+    atomicAdd(&red[1024 + row * 32 + li], acc1[r]);
+    atomicAdd(&red[2048 + row * 32 + li], acc2[r]);
+  }
+  atomicAdd(&red[3072 + li], bs_dz);
+  atomicAdd(&red[3104 + li], bs_ds);
+  __syncthreads();
+  float* out = slab + (long)blockIdx.x * WG_SLAB;
+  for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
+}
+
+// ------------------------------------------------------------------ the same pass with TRANSPOSED products: no LDS transposes
+// wn_block_bwd_dz_wgrad_mfma pushes five 32x32 tiles per time tile through LDS to turn "time on the lane" (how the data
+// lies in memory) into "channel on the lane" (what a contraction over TIME wants), holds 368 registers and runs one wave
+// per SIMD.  Here z and dz are formed TRANSPOSED instead -- the activation tile is the A operand (lane = time, loaded
+// coalesced exactly as before), the weights are the B operand:
+//     zT[t][d]  = b_dil[d] + sum_{c,k} relu(s[c][t + k*dil]) * W_dil[d][c][k]      (bit-identical to the forward's z: same
+//     dzT[t][d] = (z > 0) * sum_r dS[r][t] * W_dense[r][d]                          products, same accumulation order)
+// so the accumulators come out with the CHANNEL on the lane and time in the registers (register r of lane-half h is sample
+// t0 + mfma32_row(r, h)) -- which is precisely the A / B fragment of the weight-gradient products, whose k-steps may
+// enumerate the 32 samples of the tile in any order:
+//     dW_dil[d][c][k] += sum_t dzT[t][d] * relu(s[c][t + k*dil])      A = dzT registers,  B = s, channel on the lane
+//     dW_dense[r][d]  += sum_t dS[r][t]  * relu(zT[t][d])             A = dS, channel on the lane,  B = relu(zT) registers
+// The three channel-on-lane operands (dS, both taps of s) are a SECOND load of lines the time-on-lane loads fetch anyway:
+// lane c reads its own row as four 16-byte pieces (samples 8q + 4h .. +3), L1/L2 hits.  dz leaves as four 16-byte stores
+// per lane.  No LDS traffic inside the loop, under 256 registers: two waves per SIMD cover each other's memory latency.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // rows start at any sample: 4-byte aligned 16-byte accesses
+
+__global__ void __launch_bounds__(256, 2)
+    wn_block_bwd_dzw_t(const float* __restrict__ dS, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
+                       const float* __restrict__ w_dense, const float* __restrict__ s_in, float* __restrict__ DZ,
+                       float* __restrict__ slab, int B, int Lin, int dil) {
+  __shared__ float red[3 * 1024 + 64];
+  __shared__ float wl[32 * 65 + 32 * 33 + 32];
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  for (int i = threadIdx.x; i < 1024; i += 256) wl[2080 + (i >> 5) * 33 + (i & 31)] = w_dense[i];
+  if (threadIdx.x < 32) wl[3136 + threadIdx.x] = b_dil ? b_dil[threadIdx.x] : 0.f;
+  for (int i = threadIdx.x; i < 3 * 1024 + 64; i += 256) red[i] = 0.f;
+  __syncthreads();
+  // The weight fragments stay in LDS and are read per k-step (one conflict-free ds_read_b32 each, 48 per tile against 96
+  // MFMAs of 64 cycles): 48 registers less than keeping them resident -- that is what brings the kernel under the 256
+  // registers of two waves per SIMD.
+  //   wdp[2s]  : B[k = (c = s, tap = lh)][j = d = li] = W_dil[d][c][tap]   (the forward's A fragment)
+  //   wtp[66s] : B[k = r = 2s+lh][j = d = li]         = W_dense[r][d]
+  const float* wdp = wl + li * 65 + lh;
+  const float* wtp = wl + 2080 + lh * 33 + li;
+  const float bz = wl[3136 + li];
+
+  f32x16 acc0, acc1, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+  float bs_dz = 0.f, bs_ds = 0.f;
+
+  for (long tl = wave0; tl < ntiles; tl += nwaves) {
+    const int b = (int)(tl / tiles_per_seq);
+    const int t0 = (int)(tl - (long)b * tiles_per_seq) * 32;
+    const int t = t0 + li;
+    const bool ok = t < Lo;
+    const int tcl = ok ? t : 0;
+    const bool full = t0 + 32 <= Lo;                        // wave-uniform: every sample of the tile exists
+    // ---- time on the lane (coalesced; unconditional loads from a clamped address, masked below)
+    float x[32], g[16];
+    {
+      const float* xp = s_in + (long)b * 32 * Lin + tcl + lh * dil;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) x[c] = xp[(long)c * Lin];
+      const float* gp = dS + (long)b * 32 * Lo + tcl;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) g[q] = gp[(long)(2 * q + lh) * Lo];
+    }
+    // ---- channel on the lane: lane li reads its own row, samples t0 + mfma32_row(s, lh) = t0 + 8q + 4lh + e (s = 4q + e)
+    float gc[16], xc0[16], xc1[16];
+    const float* rowS = dS + ((long)b * 32 + li) * Lo + t0 + 4 * lh;
+    const float* rowX = s_in + ((long)b * 32 + li) * Lin + t0 + 4 * lh;
+    if (full) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f4u a = *reinterpret_cast<const f4u*>(rowS + 8 * q);
+        const f4u u = *reinterpret_cast<const f4u*>(rowX + 8 * q);
+        const f4u v = *reinterpret_cast<const f4u*>(rowX + dil + 8 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { gc[4 * q + e] = a[e]; xc0[4 * q + e] = u[e]; xc1[4 * q + e] = v[e]; }
+      }
+    } else {                                                // ragged last tile of a sequence: element-wise, clamped + masked
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int o = 8 * (s >> 2) + (s & 3);
+        const bool in = t0 + 4 * lh + o < Lo;
+        const int oc = in ? o : -(t0 + 4 * lh);             // clamp to the row's first sample
+        const float a = rowS[oc], u = rowX[oc], v = rowX[oc + dil];
+        gc[s] = in ? a : 0.f; xc0[s] = in ? u : 0.f; xc1[s] = in ? v : 0.f;
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);                      // keep every load of the tile above the MFMAs
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = ok ? relu1(x[c]) : 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) g[q] = ok ? g[q] : 0.f;
+    // ---- zT, dzT
+    f32x16 zT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) zT[r] = bz;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) zT = mfma32(x[s], wdp[2 * s], zT);
+    f32x16 dzT;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dzT[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) dzT = mfma32(g[s], wtp[66 * s], dzT);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dzT[r] = zT[r] > 0.f ? dzT[r] : 0.f;     // rows of samples beyond the sequence are zero (g = 0)
+    // ---- dz out: lane li owns row d = li
+    float* rowZ = DZ + ((long)b * 32 + li) * Lo + t0 + 4 * lh;
+    if (full) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        f4u o = {dzT[4 * q], dzT[4 * q + 1], dzT[4 * q + 2], dzT[4 * q + 3]};
+        *reinterpret_cast<f4u*>(rowZ + 8 * q) = o;
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int o = 8 * (s >> 2) + (s & 3);
+        if (t0 + 4 * lh + o < Lo) rowZ[o] = dzT[s];
+      }
+    }
+    // ---- parameter gradients: k-step s stands for sample t0 + mfma32_row(s, lh) on both operands
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { bs_dz += dzT[s]; bs_ds += gc[s]; }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc2 = mfma32(gc[s], relu1(zT[s]), acc2);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc0 = mfma32(dzT[s], relu1(xc0[s]), acc0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) acc1 = mfma32(dzT[s], relu1(xc1[s]), acc1);
   }
 
 #pragma unroll
@@ -998,7 +1152,7 @@ extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* 
       if (blocks > 512) blocks = 512;    // 2 waves per SIMD resident; each wave walks >= 5 tiles at the bench shape
       // z (pre-ReLU dilation output) is NOT kept: backward rebuilds it from s_i inside its fused kernel, bit-identically
       hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
-                           prm->dense_w_h[i], be, ws + p.s[i + 1], (float*)nullptr, B, p.L[i], dil);
+                         prm->dense_w_h[i], be, ws + p.s[i + 1], (float*)nullptr, B, p.L[i], dil);
     } else {
       float* z = ws + p.z;
       hipLaunchKernelGGL(conv1d_fwd_generic, dim3(grid1((long)B * D * p.L[i + 1])), dim3(256), 0, s, ws + p.s[i],
@@ -1117,8 +1271,17 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
         if (wb > 256) wb = 256;
         if (wb > WG_MAXBLK) wb = WG_MAXBLK;
         if (wb < 1) wb = 1;
-        hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd,
-                           prm->dense_w_h[i], si, DZ, ws + p.slab, B, Li, dil);
+        if (!avvad_tune().wn_bwd_t) {
+          hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd,
+                             prm->dense_w_h[i], si, DZ, ws + p.slab, B, Li, dil);
+        } else {
+          // alternate: transposed-product form, under 256 registers, two workgroups per CU (one wave per SIMD each)
+          wb = ((long)B * cdiv(Lo, 32) + 15) / 16;
+          if (wb > 512) wb = 512;
+          if (wb < 1) wb = 1;
+          hipLaunchKernelGGL(wn_block_bwd_dzw_t, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd, prm->dense_w_h[i], si,
+                             DZ, ws + p.slab, B, Li, dil);
+        }
         hipLaunchKernelGGL(wn_wgrad_reduce, dim3(cdiv(WG_SLAB, 256), 32), dim3(256), 0, s, ws + p.slab, (int)wb, g->dil_w_h[i],
                            d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
                            d->use_bias ? g->dense_b_h[i] : (float*)nullptr);

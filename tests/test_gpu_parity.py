@@ -153,9 +153,13 @@ def test_engine_streamk_fixup_equals_whole_tile(M, N, K):
 
 
 # ------------------------------------------------------------------------------------------ WaveNet encoder
-@pytest.mark.parametrize("name", ["wn_tiny", "wn_fw3_qc2", "wn_nobias", "wn_w0", "wn_w0_t16"])
-def test_wavenet_golden(name):
+@pytest.mark.parametrize("name,alt", [("wn_tiny", 0), ("wn_fw3_qc2", 0), ("wn_nobias", 0), ("wn_w0", 0), ("wn_w0_t16", 0),
+                                      ("wn_nobias", 1), ("wn_w0", 1), ("wn_w0_t16", 1)])
+def test_wavenet_golden(name, alt, lib_options):
+    """alt=1: the alternate block backward kept in the library (transposed products, no LDS transposes)."""
     from packages.models.wavenet_autoencoder import wavenet_autoencoder
+    if alt:
+        lib_options("wn_bwd_t", 1)
     g = load_golden(name)
     cfg = wn_cfg_from(g)
     m = wavenet_autoencoder(**cfg)
