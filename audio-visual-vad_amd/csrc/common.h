@@ -37,6 +37,7 @@ struct AvvadTune {
   int wn_no_fused_tail;     // unfused encoder tail backward
   int wn_no_fused_wgrad;    // unfused encoder block backward (dz, weight gradients as separate kernels)
   int wn_bwd_t;             // alternate block backward: transposed products (no LDS transposes), 250 registers, 2 waves / SIMD
+  int bf16;                 // bf16-input MFMA (fp32 accumulate) for the convolutions and dense GEMMs: BASELINE config 5's arithmetic
   int max_cus;              // cap on the CUs a persistent grid occupies (0 = all 256): leaves room for RCCL kernels
 };
 AvvadTune& avvad_tune();

@@ -137,12 +137,24 @@ template <class Op>
 struct HasPost<Op, std::void_t<decltype(&Op::post)>> : std::true_type {};
 
 // ---------------------------------------------------------------- the kernel
+// bf16 operands (option "bf16", BASELINE config 5): the fp32 values are rounded to bf16 (RNE) on their way into LDS and
+// multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 16x the matrix rate of the fp32-input instruction.  That
+// instruction wants 8 CONSECUTIVE k per lane (lane half h: k = 8h .. 8h+7 of a 16-deep step), so the bf16 LDS image is
+// x-major: one row per m (or n) of BK = 32 bf16 = 64 bytes, padded to 80 bytes (20 words: the 16 lanes of a ds_read_b128
+// phase then cover all 64 banks exactly once).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+constexpr int LDH = 40;   // halfwords per LDS row of the bf16 image
+
 template <class Op, int BX, int NTH>
 struct Stage {
   static constexpr int VEC = Op::VEC;
   static constexpr int NV = BX * BK / (NTH * VEC);
   static constexpr int LD = Op::KCONTIG ? BX + 1 : BX + 4;
   static constexpr int NCTX = Op::KCONTIG ? NV : 1;
+  static constexpr int TILE_F32 = BK * LD;                 // floats of the fp32 (k-major) image
+  static constexpr int TILE_BF = BX * LDH / 2;             // floats' worth of the bf16 (x-major) image
   // thread -> (x_local, k_local) of its i-th vector
   __device__ static __forceinline__ void coord(int t, int i, int& xl, int& kl) {
     if (Op::KCONTIG) {
@@ -177,6 +189,32 @@ struct Stage {
       }
     }
   }
+  // the bf16 image: S16[x][k]
+  __device__ static __forceinline__ void to_lds_bf(__bf16* S, int t, const float (&st0)[NV][VEC], const Op& op, unsigned okmask) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int xl, kl;
+      coord(t, i, xl, kl);
+      float st[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float v = st0[i][j];
+        if constexpr (HasPost<Op>::value) v = op.post(v);
+        st[j] = ((okmask >> i) & 1u) ? v : 0.f;
+      }
+      if (Op::KCONTIG) {
+        if constexpr (VEC == 4) {                // four consecutive k of one row: one 8-byte store
+          const f32x4v f = {st[0], st[1], st[2], st[3]};
+          *reinterpret_cast<bf16x4*>(S + xl * LDH + kl) = __builtin_convertvector(f, bf16x4);
+        } else {
+          S[xl * LDH + kl] = (__bf16)st[0];
+        }
+      } else {                                   // consecutive x at one k: the transposition costs 2-byte stores
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) S[(xl + j) * LDH + kl] = (__bf16)st[j];
+      }
+    }
+  }
 };
 
 // Work decomposition: data-parallel rounds + one "stream-K" round.  The launch creates G persistent workgroups
@@ -196,7 +234,7 @@ struct Stage {
 // budget of 4 waves/SIMD the 8-wave kernels spill, 5 % slower end to end).
 // NTH = 256: 4 waves as 2x2, each (BM/2)x(BN/2);  NTH = 512: 8 waves as 2x4, each (BM/2)x(BN/4) -- half the
 // accumulators and staging registers per wave, so twice the waves per SIMD fit next to the same LDS tile.
-template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi>
+template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi, bool BF = false>
 // (HIP's second launch-bounds argument is WAVES PER SIMD, not blocks per CU.  The 8-wave instantiation is pinned to
 //  4 waves/SIMD = the 2 workgroups/CU launch() assumes: a build drifting past 128 VGPRs would otherwise silently halve
 //  the residency -- the instrumented -DAVVAD_PROF build did exactly that.  The 4-wave instantiations are left looser:
@@ -211,8 +249,19 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
   constexpr int WGN = (BM == 256) ? 2 : NTH / 128;
   constexpr int WGM = NTH / 64 / WGN;
   constexpr int TM = BM / (32 * WGM), TN = BN / (32 * WGN);
-  constexpr int TILE = BK * SA::LD + BK * SB::LD;
+  constexpr int TILE = BF ? SA::TILE_BF + SB::TILE_BF : BK * SA::LD + BK * SB::LD;
+  constexpr int AOFF = BF ? SA::TILE_BF : BK * SA::LD;     // floats from a tile's A image to its B image
+  const int t_stage = threadIdx.x;
   __shared__ __attribute__((aligned(16))) float smem[(DB ? 2 : 1) * TILE];
+  auto stage = [&](float* dst, const float (&ra)[SA::NV][SA::VEC], const float (&rb)[SB::NV][SB::VEC], unsigned ma, unsigned mb) {
+    if constexpr (BF) {
+      SA::to_lds_bf(reinterpret_cast<__bf16*>(dst), t_stage, ra, A, ma);
+      SB::to_lds_bf(reinterpret_cast<__bf16*>(dst + AOFF), t_stage, rb, B, mb);
+    } else {
+      SA::to_lds(dst, t_stage, ra, A, ma);
+      SB::to_lds(dst + AOFF, t_stage, rb, B, mb);
+    }
+  };
 
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
@@ -316,14 +365,39 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
     unsigned long long tbar = 0, tstage = 0;
     gload(kt0);
     __syncthreads();  // the previous segment's LDS reads are done
-    SA::to_lds(smem, t, sa, A, oka);
-    SB::to_lds(smem + BK * SA::LD, t, sb, B, okb);
+    stage(smem, sa, sb, oka, okb);
     if (kt0 + 1 < kt1) gload(kt0 + 1);
     __syncthreads();
     const unsigned long long tp1 = PROF_T();
 
     for (int kt = kt0; kt < kt1; ++kt) {
       const int cur = DB ? ((kt - kt0) & 1) : 0;
+      if constexpr (BF) {
+        // bf16: two 16-deep k-steps per K tile; a fragment is one ds_read_b128 (8 bf16 of row m / column n)
+        const __bf16* As16 = reinterpret_cast<const __bf16*>(smem + cur * TILE);
+        const __bf16* Bs16 = reinterpret_cast<const __bf16*>(smem + cur * TILE + AOFF);
+        const __bf16* ap = As16 + (wm * (BM / WGM) + li) * LDH + lh * 8;
+        const __bf16* bp = Bs16 + (wn * (BN / WGN) + li) * LDH + lh * 8;
+        bf16x8 a[2][TM], b[2][TN];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) a[ks][i] = *reinterpret_cast<const bf16x8*>(ap + i * 32 * LDH + ks * 16);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) b[ks][j] = *reinterpret_cast<const bf16x8*>(bp + j * 32 * LDH + ks * 16);
+        }
+        if (DB && kt + 1 < kt1) {        // stage tile kt+1 into the other buffer, request tile kt+2: under this tile's MFMAs
+          stage(smem + (cur ^ 1) * TILE, sa, sb, oka, okb);
+          if (kt + 2 < kt1) gload(kt + 2);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i], b[ks][j], acc[i][j], 0, 0, 0);
+      } else {
       float* As = smem + cur * TILE;
       float* Bs = As + BK * SA::LD;
       const float* ap = As + lh * SA::LD + wm * (BM / WGM) + li;
@@ -343,8 +417,7 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
           float* An = smem + (cur ^ 1) * TILE;
           const unsigned long long ts0 = PROF_T();
 #ifndef AVVAD_ABL_NOLDSW
-          SA::to_lds(An, t, sa, A, oka);
-          SB::to_lds(An + BK * SA::LD, t, sb, B, okb);
+          stage(An, sa, sb, oka, okb);
 #endif
 #ifndef AVVAD_ABL_NOGLOAD
           if (kt + 2 < kt1) gload(kt + 2);
@@ -367,14 +440,14 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
 #pragma unroll
           for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[ks & 1][i], b[ks & 1][j], acc[i][j]);
       }
+      }
 #ifndef AVVAD_ABL_NOBAR
       const unsigned long long tb0 = PROF_T();
       __syncthreads();
       tbar += PROF_T() - tb0;
 #endif
       if (!DB && kt + 1 < kt1) {  // single LDS buffer (more workgroups per CU): restage after everyone has read
-        SA::to_lds(smem, t, sa, A, oka);
-        SB::to_lds(smem + BK * SA::LD, t, sb, B, okb);
+        stage(smem, sa, sb, oka, okb);
         if (kt + 2 < kt1) gload(kt + 2);
         __syncthreads();
       }
@@ -478,25 +551,28 @@ __global__ void __launch_bounds__(256)
   constexpr int STRIPS = BM * BN / 256;                  // 256-element strips per tile
   __shared__ float4 part[3][64];
   const int tr = blockIdx.x / STRIPS, strip = blockIdx.x % STRIPS;
-  const long R = (long)rem_tiles * ktiles;
-  // worker of iteration it: shares are [g*R/G, (g+1)*R/G)  ->  g = ceil((it+1)*G/R) - 1
-  const long it0 = (long)tr * ktiles, it1 = it0 + ktiles - 1;
-  const long ga = ((it0 + 1) * G + R - 1) / R - 1, gb = ((it1 + 1) * G + R - 1) / R - 1;
+  // worker of iteration it: shares are [g*R/G, (g+1)*R/G)  ->  g = ceil((it+1)*G/R) - 1.  All of this is block-uniform and
+  // in 32 bits (the host launches this kernel only when R * G < 2^32: a 64-bit software division per thread and slab was
+  // most of this kernel's time in its first version).
+  const unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, Gu = (unsigned)G;
+  const unsigned it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  const int ga = (int)(((it0 + 1u) * Gu + R - 1u) / R) - 1, gb = (int)(((it1 + 1u) * Gu + R - 1u) / R) - 1;
   if (gb <= ga) return;                                  // the tile was not split
+  const bool sparse = R < Gu;                            // fewer iterations than workers: some shares are empty
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e0 = strip * 256 + lane * 4;                 // tile-local element (row-major [BM][BN]) of this lane's float4
   const float* S0 = slab + e0;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-  // (a worker whose share is empty -- fewer iterations than workers -- wrote no slab: its slot is skipped; shares are
-  //  contiguous, so every non-empty worker between ga and gb lies inside this tile)
-  for (long g = ga + 1 + wave; g <= gb; g += 16) {
+  // (a worker whose share is empty wrote no slab: its slot is skipped; shares are contiguous, so every non-empty worker
+  //  between ga and gb lies inside this tile)
+  for (int g = ga + 1 + wave; g <= gb; g += 16) {
     float4 v[4];
     bool ok[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const long gu = g + 4 * u;
-      ok[u] = gu <= gb && (gu + 1) * R / G > gu * R / G;
-      v[u] = *reinterpret_cast<const float4*>(S0 + (ok[u] ? gu : ga + 1) * (long)(BM * BN));
+      const int gu = g + 4 * u;
+      ok[u] = gu <= gb && (!sparse || ((unsigned)(gu + 1) * R) / Gu > ((unsigned)gu * R) / Gu);
+      v[u] = *reinterpret_cast<const float4*>(S0 + (long)(ok[u] ? gu : ga + 1) * (BM * BN));
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u)
@@ -507,8 +583,8 @@ __global__ void __launch_bounds__(256)
   if (wave > 0) return;
 #pragma unroll
   for (int w = 0; w < 3; ++w) { const float4 p = part[w][lane]; sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w; }
-  const long tile = (long)full_rounds * G + tr;
-  const int m = (int)(tile / ntn) * BM + e0 / BN, n0 = (int)(tile % ntn) * BN + e0 % BN;
+  const unsigned tile = (unsigned)full_rounds * Gu + (unsigned)tr;
+  const int m = (int)(tile / (unsigned)ntn) * BM + e0 / BN, n0 = (int)(tile % (unsigned)ntn) * BN + e0 % BN;
   if (m >= M) return;
   const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
 #pragma unroll
@@ -526,9 +602,10 @@ constexpr size_t SLAB_FLOATS = (size_t)512 * 128 * 128;
 // it is cut K-major (see the kernel); everything else is scheduled as data-parallel rounds + one stream-K round.
 // `slab`: SLAB_FLOATS floats of scratch for the split tiles of the stream-K round; nullptr selects whole-tile scheduling
 // (slower on tile counts that quantise badly, still deterministic).
+// `allow_bf16`: the process-wide option "bf16" applies to this product (false for the STFT, whose DFT stays exact fp32).
 template <int BM, int BN, class AOp, class BOp, class Epi>
 static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N, int K, int split_k_hint,
-                         hipStream_t s, float* slab = nullptr) {
+                         hipStream_t s, float* slab = nullptr, bool allow_bf16 = true) {
   if (M <= 0 || N <= 0 || K <= 0) return AVVAD_EINVAL;
   const int ktiles = (K + BK - 1) / BK;
   const long ntiles = (long)cdiv(M, BM) * cdiv(N, BN);
@@ -547,7 +624,8 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   const int cus = (tn.max_cus > 0 && tn.max_cus < NUM_CU) ? tn.max_cus : NUM_CU;   // room for RCCL's kernels at N > 1
   long G = (long)cus * per_cu;
   if (G * BM * BN > (long)SLAB_FLOATS) G = (long)(SLAB_FLOATS / ((size_t)BM * BN));
-  const bool no_sk = !slab || tn.no_streamk == 1 || tn.no_streamk == 10 + e.mode;   // whole-tile schedule
+  const bool no_sk = !slab || tn.no_streamk == 1 || tn.no_streamk == 10 + e.mode ||   // whole-tile schedule
+                     (double)ntiles * ktiles * (double)G >= 4.0e9;                     // (fix-up index math is 32-bit)
   long full_rounds = ntiles / G, rem = ntiles - full_rounds * G;
   int kchunks = 0;
   // OFF by default (option "kmajor"): it removes most of the wgrad kernel's beyond-L2 fetches, but the
@@ -578,17 +656,24 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
     }
   }
   const int fr = (int)full_rounds, rt = (int)rem;
+  const bool bf = allow_bf16 && tn.bf16;
+#define AVVAD_IGEMM_LAUNCH(DBV, NTHV)                                                                                       \
+  do {                                                                                                                      \
+    if (bf)                                                                                                                 \
+      hipLaunchKernelGGL((kernel<BM, BN, DBV, NTHV, AOp, BOp, Epi, true>), dim3((int)G), dim3(NTHV), 0, s, a, b, e, M, N, K, \
+                         ktiles, fr, rt, kchunks, slab);                                                                    \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((kernel<BM, BN, DBV, NTHV, AOp, BOp, Epi, false>), dim3((int)G), dim3(NTHV), 0, s, a, b, e, M, N, K, \
+                         ktiles, fr, rt, kchunks, slab);                                                                    \
+  } while (0)
   if constexpr (TALL) {
-    hipLaunchKernelGGL((kernel<BM, BN, false, 512, AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks, slab);
+    AVVAD_IGEMM_LAUNCH(false, 512);
   } else {
-    if (variant == 0)
-      hipLaunchKernelGGL((kernel<BM, BN, true, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks, slab);
-    else if (variant == 1 || !BIG)
-      hipLaunchKernelGGL((kernel<BM, BN, false, 256, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, M, N, K, ktiles, fr, rt, kchunks, slab);
-    else
-      hipLaunchKernelGGL((kernel<BM, BN, true, (BIG ? 512 : 256), AOp, BOp, Epi>), dim3((int)G), dim3(512), 0, s, a, b, e, M, N, K,
-                         ktiles, fr, rt, kchunks, slab);
+    if (variant == 0) AVVAD_IGEMM_LAUNCH(true, 256);
+    else if (variant == 1 || !BIG) AVVAD_IGEMM_LAUNCH(false, 256);
+    else AVVAD_IGEMM_LAUNCH(true, (BIG ? 512 : 256));
   }
+#undef AVVAD_IGEMM_LAUNCH
   if (rt > 0 && kchunks == 0)
     hipLaunchKernelGGL((fixup<BM, BN, Epi>), dim3(rt * (BM * BN / 256)), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));
   AVVAD_LAUNCH_CHECK();

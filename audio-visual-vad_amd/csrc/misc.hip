@@ -21,6 +21,7 @@ const OptName kOpts[] = {
     {"wn_no_fused_tail", "AVVAD_WN_NO_FUSED_TAIL", &AvvadTune::wn_no_fused_tail},
     {"wn_no_fused_wgrad", "AVVAD_WN_NO_FUSED_WGRAD", &AvvadTune::wn_no_fused_wgrad},
     {"wn_bwd_t", "AVVAD_WN_BWD_T", &AvvadTune::wn_bwd_t},
+    {"bf16", "AVVAD_BF16", &AvvadTune::bf16},
     {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
 };
 int parse_opt(const char* name, const char* v) {

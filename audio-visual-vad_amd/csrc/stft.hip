@@ -130,7 +130,7 @@ static int stft_impl(const float* wave, float* out, const avvad_stft_desc* d, in
   FrameRows a{wave, d->L, M, d->n_fft, d->T, d->hop};
   igemm::ColPlain<4> b{W, ld, ld, d->n_fft, 0};
   igemm::EpiStore e{S, ld, nullptr, 0};
-  int rc = igemm::launch<128, 128>(a, b, e, M, ld, d->n_fft, 1, s, S + align_up((size_t)M * ld, 64));
+  int rc = igemm::launch<128, 128>(a, b, e, M, ld, d->n_fft, 1, s, S + align_up((size_t)M * ld, 64), /*allow_bf16=*/false);
   if (rc) return rc;
   if (mode == 2) hipLaunchKernelGGL(to_legacy_view, dim3(grid1((long)d->T * F * 2)), dim3(256), 0, s, S, out, d->T, F, ld);
   else if (mean)

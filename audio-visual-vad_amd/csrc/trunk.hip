@@ -125,6 +125,38 @@ __global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wf
     if (wd) wd[((long)(kh * KS + kw) * Co + co) * C + c] = v;
   }
 }
+// all 20 convolutions' weights in ONE launch (19 separate launches of ~9 us each were 0.17 ms of a 22 ms step): the block
+// index selects the convolution through a small table of block ranges
+struct PackTab {
+  const float* w[NCONV];
+  float* wf[NCONV];
+  float* wd[NCONV];      // may be null
+  int cout[NCONV], cin[NCONV], ks[NCONV];
+  int blk0[NCONV + 1];   // first block of conv i (conv 0 = stem: its 3 input channels are folded, see pack_stem)
+};
+__global__ void __launch_bounds__(256) pack_all(const PackTab tab) {
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < NCONV; ++j) i += (int)blockIdx.x >= tab.blk0[j];      // block-uniform
+  const int e = ((int)blockIdx.x - tab.blk0[i]) * 256 + threadIdx.x;
+  const float* w = tab.w[i];
+  float* wf = tab.wf[i];
+  if (i == 0) {
+    if (e >= 64 * 49) return;
+    const int co = e / 49, k = e % 49;
+    wf[k * 64 + co] = w[(co * 3 + 0) * 49 + k] + w[(co * 3 + 1) * 49 + k] + w[(co * 3 + 2) * 49 + k];
+    return;
+  }
+  const int Co = tab.cout[i], C = tab.cin[i], KS = tab.ks[i];
+  if (e >= Co * C * KS * KS) return;
+  int r = e;
+  const int kw = r % KS; r /= KS;
+  const int kh = r % KS; r /= KS;
+  const int c = r % C; const int co = r / C;
+  const float v = w[e];
+  wf[((long)(kh * KS + kw) * C + c) * Co + co] = v;
+  if (tab.wd[i]) tab.wd[i][((long)(kh * KS + kw) * Co + co) * C + c] = v;
+}
 // stem: fold the 3 identical input channels (Video_Net.py:64): Wf[kh*7+kw][co] = sum_c w[co][c][kh][kw]
 __global__ void pack_stem(const float* __restrict__ w, float* __restrict__ wf) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -542,12 +574,20 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
   float* ws = (float*)wsv;
   int rc;
   // weights: OIHW -> packed
-  hipLaunchKernelGGL(pack_stem, dim3(cdiv(64 * 49, 256)), dim3(256), 0, s, prm->conv_w[0], ws + p.wf[0]);
-  for (int i = 1; i < NCONV; ++i) {
-    const ConvSpec& c = p.conv[i];
-    const int n = c.cout * c.cin * c.ks * c.ks;
-    hipLaunchKernelGGL(pack_weights, dim3(ew_grid(n)), dim3(256), 0, s, prm->conv_w[i], ws + p.wf[i],
-                       d->save_for_backward ? ws + p.wd[i] : (float*)nullptr, c.cout, c.cin, c.ks);
+  {
+    PackTab tab;
+    int nb = 0;
+    for (int i = 0; i < NCONV; ++i) {
+      const ConvSpec& c = p.conv[i];
+      tab.w[i] = prm->conv_w[i];
+      tab.wf[i] = ws + p.wf[i];
+      tab.wd[i] = (i > 0 && d->save_for_backward) ? ws + p.wd[i] : (float*)nullptr;
+      tab.cout[i] = c.cout; tab.cin[i] = c.cin; tab.ks[i] = c.ks;
+      tab.blk0[i] = nb;
+      nb += cdiv(i == 0 ? 64 * 49 : (long)c.cout * c.cin * c.ks * c.ks, 256);
+    }
+    tab.blk0[NCONV] = nb;
+    hipLaunchKernelGGL(pack_all, dim3(nb), dim3(256), 0, s, tab);
   }
   // stem
   const long N = d->N;

@@ -587,6 +587,113 @@ def test_stft_frontend_gpu(L):
         stft_pytorch(x.to(DEV), fs=16e3, wlen_sec=64e-3, win=torch.ones(1024, device=DEV), center=False)
 
 
+# ------------------------------------------------------------------------------------------ bf16 arithmetic (BASELINE configs[4])
+@pytest.mark.parametrize("N,H,W,C,Co,KS,stride,pad", [(3, 17, 17, 64, 64, 3, 1, 1), (2, 17, 17, 64, 128, 3, 2, 1), (5, 9, 9, 128, 128, 3, 1, 1),
+                                                      (2, 17, 17, 64, 128, 1, 2, 0), (4, 3, 3, 512, 512, 3, 1, 1), (700, 9, 9, 128, 128, 3, 1, 1)])
+def test_bf16_convolutions_vs_rounded_operands(N, H, W, C, Co, KS, stride, pad, lib_options):
+    """Option "bf16": operands are rounded to bf16 (round to nearest even) on their way into LDS, multiplied by
+    v_mfma_f32_32x32x16_bf16, accumulated in fp32.  Exact check of that arithmetic: F.conv2d in fp32 on operands that
+    were rounded to bf16 BEFOREHAND has the very same products, so only the fp32 summation order differs (1e-5-level) --
+    a wrong k-slot, lane or row in the bf16 LDS image would be an O(1) error.  Forward, data gradient, weight gradient."""
+    import ctypes as Ct
+    import torch.nn.functional as F
+    from avvad import _lib as L, ops
+    lib_options("bf16", 1)
+    rng = np.random.RandomState(N * H + C + 1)
+    r16 = lambda t: t.bfloat16().float()
+    x = r16(T(rng.normal(size=(N, C, H, W)).astype(np.float32))).requires_grad_(True)
+    w = r16(T((rng.normal(size=(Co, C, KS, KS)) / np.sqrt(C * KS * KS)).astype(np.float32))).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, pad)
+    gy = r16(T(rng.normal(size=tuple(y.shape)).astype(np.float32)))
+    y.backward(gy)
+    lib = L.lib()
+    st = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(N, H, W, C, Co, KS, stride, pad)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    wf = torch.empty(KS * KS * C * Co, device=DEV)
+    wdg = torch.empty(KS * KS * C * Co, device=DEV)
+    L.check(lib.avvad_conv2d_pack_weights(L.ptr(w.detach().to(DEV)), L.ptr(wf), L.ptr(wdg), Ct.byref(d), st), "pack")
+    ews = ops.engine_ws(DEV)
+    wsz = ews.numel() * 4
+    yd = torch.empty(N, y.shape[2], y.shape[3], Co, device=DEV)
+    L.check(lib.avvad_conv2d_fwd(L.ptr(xd), L.ptr(wf), L.ptr(yd), Ct.byref(d), L.ptr(ews), wsz, st), "fwd")
+    tag = "bf16 conv %dx%dx%dx%d->%d k%d s%d" % (N, H, W, C, Co, KS, stride)
+    _report(tag + " fwd", yd.permute(0, 3, 1, 2), y, 2e-5, 2e-5)
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = torch.empty_like(xd)
+    L.check(lib.avvad_conv2d_dgrad(L.ptr(gyd), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 0, L.ptr(ews), wsz, st), "dgrad")
+    _report(tag + " dgrad", dx.permute(0, 3, 1, 2), x.grad, 2e-5, 2e-5)
+    dw = torch.empty(KS * KS * C, Co, device=DEV)
+    L.check(lib.avvad_conv2d_wgrad(L.ptr(xd), L.ptr(gyd), L.ptr(dw), Ct.byref(d), L.ptr(ews), wsz, st), "wgrad")
+    _report(tag + " wgrad", dw, w.grad.permute(2, 3, 1, 0).reshape(KS * KS * C, Co), 1e-4 * np.sqrt(N), 1e-4)
+    # and the distance to the UNROUNDED fp32 product is what bf16 operands cost: ~3e-3 relative
+    y32 = F.conv2d(x.detach(), w.detach(), None, stride, pad)
+    assert float((yd.permute(0, 3, 1, 2).cpu() - y32).norm() / y32.norm()) < 1e-5      # (operands already representable)
+
+
+def test_bf16_gemm_variants(lib_options):
+    from avvad import ops
+    lib_options("bf16", 1)
+    rng = np.random.RandomState(5)
+    for (M, N, K, tA, tB) in [(128, 128, 64, 0, 1), (100, 70, 513, 0, 1), (64, 4096, 1024, 0, 1), (37, 130, 96, 0, 0), (130, 64, 40, 1, 0),
+                              (4096, 513, 48, 1, 0), (1025, 300, 7, 1, 1), (1024, 768, 4096, 0, 0)]:
+        A = T(rng.normal(size=(K, M) if tA else (M, K)).astype(np.float32)).bfloat16().float()
+        B = T(rng.normal(size=(N, K) if tB else (K, N)).astype(np.float32)).bfloat16().float()
+        ref = (A.t() if tA else A).double() @ (B.t() if tB else B).double()
+        c = torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(DEV), B.to(DEV), c, M, N, K, A.shape[1], B.shape[1], N, bool(tA), bool(tB))
+        _report("bf16 gemm %dx%dx%d tA%d tB%d" % (M, N, K, tA, tB), c, ref, 1e-5 * np.sqrt(K) * 4)
+    # unrounded operands: the bf16 rounding itself, relative L2 ~ 2^-9 * sqrt(2)
+    A = T(rng.normal(size=(512, 768)).astype(np.float32)); B = T(rng.normal(size=(768, 640)).astype(np.float32))
+    c = torch.empty(512, 640, device=DEV)
+    ops.gemm(A.to(DEV), B.to(DEV), c, 512, 640, 768, 768, 640, 640)
+    rel = float((c.cpu().double() - A.double() @ B.double()).norm() / (A.double() @ B.double()).norm())
+    print("bf16 gemm on fp32 operands: relL2 %.2e" % rel)
+    assert 5e-4 < rel < 6e-3
+
+
+def test_bf16_av_training_step_vs_fp32_oracle(lib_options):
+    """BASELINE configs[4] arithmetic end to end on the AV model (WaveNet encoder + trunk + LSTM head): bf16 operands in
+    every convolution / dense GEMM, fp32 BatchNorm statistics, LSTM cell, loss.  SURVEY 7's tolerance for this mode: about
+    2e-2 relative on the logits vs the fp32 oracle; gradients must point the same way: cosine > 0.9 on every big tensor
+    (measured: 0.96 on the stem weights, whose gradient has passed 20 bf16 convolutions and train-mode BatchNorm over
+    only 12 frames; > 0.99 on the head)."""
+    from oracle import head, models
+    from packages.models.AV_Net import DeepVAD_AV
+    from packages.models.utils import batch_binary_cross_entropy
+    wcfg = dict(filter_width=2, quantization_channel=1, dilations=[1, 2, 4, 8, 16, 32], en_residual_channel=32,
+                en_dilation_channel=32, en_bottleneck_width=64, en_pool_kernel_size=4, use_bias=True)
+    torch.manual_seed(5)
+    m = DeepVAD_AV(2, 32, 1, wavenet_params=wcfg)
+    B, Tn = 3, 4
+    wave = torch.randn(B, 1, Tn * 256 + 63) * 0.3
+    video = torch.randn(B, Tn, 67, 67)
+    tgt = (torch.rand(B, Tn, 1) > 0.5).float()
+    lens = [4, 2, 3]
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.detach().clone())
+          for k, v in m.state_dict().items()}
+    ref = models.av_net(sd, wave, video, lens, 2, training=True, wavenet_cfg=wcfg)
+    ref_loss = head.batch_loss(ref, tgt, lens, 1e-8)
+    ref_loss.backward()
+    lib_options("bf16", 1)
+    m = m.to(DEV).train()
+    y = m(wave.to(DEV), video.to(DEV), torch.LongTensor(lens))
+    scale = float(ref.abs().max())
+    _report("bf16 AV logits vs fp32 oracle", y, ref, 2e-2 * scale)
+    loss = batch_binary_cross_entropy(y, tgt.to(DEV), lens, 1e-8)
+    _report("bf16 AV loss", loss, ref_loss, 2e-2 * float(ref_loss))
+    loss.backward()
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        g, r = p.grad.cpu().flatten().double(), sd[k].grad.flatten().double()
+        assert torch.isfinite(g).all(), k
+        if r.numel() >= 4096:
+            cos = float((g @ r) / (g.norm() * r.norm()).clamp_min(1e-30))
+            print("bf16 grad cosine %-40s %.4f" % (k, cos))
+            assert cos > 0.9, (k, cos)
+
+
 # ------------------------------------------------------------------------------------------ boundary: bare modules, losses
 def test_count_sketch_and_compact_bilinear_pooling_modules():
     """``CountSketch.forward`` / ``CompactBilinearPooling.forward`` as stand-alone modules (compact_bilinear_pooling.py
