@@ -156,7 +156,7 @@ def _events(torch, fn, reps):
     return e0.elapsed_time(e1) / reps      # ms
 
 
-def roofline_probe(torch, n_frames, reps=5):
+def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
     """Per-launch duration (HIP events on the launch stream = torch's current stream) of the dominant kernel: the
     fp32-MFMA implicit-GEMM convolution igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,...>, i.e. the forward of
     every trunk conv with Cout >= 128 (15 launches per step).  achieved = algorithmic FLOPs of those launches
@@ -185,10 +185,12 @@ def roofline_probe(torch, n_frames, reps=5):
         tot_ms += ms
         n_launch += 1
     ach = tot_flop / tot_ms / 1e9
-    return {"bound": "mfma", "kernel": "igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,EpiStore> (trunk conv forward, Cout>=128)",
+    peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
+    return {"bound": "mfma", "kernel": "igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,EpiStore%s> (trunk conv forward, Cout>=128) + its "
+                                       "stream-K fix-up" % (",bf16" if dtype == "bf16" else ""),
             "launches_per_step": n_launch, "avg_launch_us": round(1e3 * tot_ms / n_launch, 2),
-            "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4),
-            "traffic": TRAFFIC.get("conv_fwd"),
+            "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": TRAFFIC.get("conv_fwd") if dtype == "f32" else None,
             "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC, profiles/r02_pmc_*_per_kernel.csv)",
             "per_shape": [{"C": a, "Co": b, "HW": c_, "k": d_, "s": e, "us": round(1e3 * f, 1), "TFLOPs": round(g, 1)}
                           for (a, b, c_, d_, e, f, g) in per]}
@@ -382,7 +384,9 @@ def main():
                "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * t_step, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": cfg["what"] if not args.forward_only else cfg["what"].replace("training step", "inference forward"),
+               "config": {"workload": cfg["what"] if not args.forward_only else
+                          cfg["what"].replace("training step", "inference forward").replace(", masked BCE, backward, RCCL all-reduce, fused Adam", "")
+                          .replace(", masked BCE, backward, fused Adam", ""),
                           "name": args.config, "per_gpu_frame_pairs": n_seq * T, "global_frame_pairs": fp_per_step,
                           "sequences_per_gpu": n_seq, "frames_per_sequence": T, "samples_per_sequence": cfg["L"],
                           "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
@@ -391,7 +395,7 @@ def main():
                           "algorithmic_tflop_per_step": round(flops / 1e12, 4), "layerwise_gb_per_step": round(byts / 1e9, 3)}}
         if not args.no_extras:
             if kind != "audio":
-                out["roofline"] = roofline_probe(torch, n_seq * T)
+                out["roofline"] = roofline_probe(torch, n_seq * T, dtype=args.dtype)
             hb = roofline_probe_hbm(torch, n_seq if kind != "video" else 64, cfg["L"] or (16 * HOP + RF - 1))
             if hb is not None:
                 out["roofline_hbm" if "roofline" in out else "roofline"] = hb

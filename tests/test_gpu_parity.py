@@ -152,6 +152,20 @@ def test_engine_streamk_fixup_equals_whole_tile(M, N, K):
     _report("engine %dx%dx%d accumulate" % (M, N, K), acc, outs[0] - bias + 0.5, 2e-5 * np.sqrt(K), 1e-5)
 
 
+def test_engine_cu_cap_option(lib_options):
+    """option max_cus (bench.py --reserve-cus): the persistent grids of the GEMM engine leave CUs free for RCCL's kernels at
+    N > 1; a different worker count is a different split of the same sums."""
+    from avvad import ops
+    rng = np.random.RandomState(3)
+    A, B = T(rng.normal(size=(20000, 300)).astype(np.float32)).to(DEV), T(rng.normal(size=(300, 256)).astype(np.float32)).to(DEV)
+    c0 = torch.empty(20000, 256, device=DEV)
+    ops.gemm(A, B, c0, 20000, 256, 300, 300, 256, 256)
+    lib_options("max_cus", 232)
+    c1 = torch.empty(20000, 256, device=DEV)
+    ops.gemm(A, B, c1, 20000, 256, 300, 300, 256, 256)
+    _report("engine with 232 of 256 CUs", c1, c0, 2e-4, 1e-5)
+
+
 # ------------------------------------------------------------------------------------------ WaveNet encoder
 @pytest.mark.parametrize("name,alt", [("wn_tiny", 0), ("wn_fw3_qc2", 0), ("wn_nobias", 0), ("wn_w0", 0), ("wn_w0_t16", 0),
                                       ("wn_nobias", 1), ("wn_w0", 1), ("wn_w0_t16", 1)])
