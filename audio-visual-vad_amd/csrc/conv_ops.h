@@ -36,74 +36,90 @@ struct TapDiv {
 static inline TapDiv tap_div(int T, int KS) { return TapDiv{div_magic((unsigned)T), div_magic((unsigned)KS)}; }
 
 // ---- forward A: rows = output pixels, K = (kh,kw,c), c contiguous (16-byte loads)
+// Context per staged vector: the BYTE offset of (window origin, channel kin) and one validity bit per tap.  A K tile is
+// one tap of one 32-channel chunk (wave-uniform), so load() adds a scalar tap offset and tests one bit.
+// (host: the activation tensor is < 4 GiB -- 32-bit byte offsets -- and KS*KS <= 32)
 struct Im2colFwd {
   static constexpr bool KCONTIG = true;
   static constexpr int VEC = 4;
-  struct Ctx { int base, hi0, wi0; };
+  struct Ctx { unsigned boff, mask; };
   const float* x;
   Geom g;
   int M;
   TapDiv td;
-  __device__ __forceinline__ Ctx prep(int m) const {
+  __device__ __forceinline__ Ctx prep(int m) const { return prep2(m, 0); }
+  __device__ __forceinline__ Ctx prep2(int m, int kin) const {
     Ctx c;
-    if (m >= M) { c.base = -1; c.hi0 = c.wi0 = 0; return c; }
+    c.boff = 0u; c.mask = 0u;
+    if (m >= M) return c;
     const int hw = g.Ho * g.Wo;
     const int n = m / hw, r = m - n * hw;
     const int ho = r / g.Wo, wo = r - ho * g.Wo;
-    c.base = n * g.H * g.W;
-    c.hi0 = ho * g.stride - g.pad;
-    c.wi0 = wo * g.stride - g.pad;
+    const int hi0 = ho * g.stride - g.pad, wi0 = wo * g.stride - g.pad;
+    c.boff = (unsigned)((((n * g.H + hi0) * g.W + wi0) * g.C + kin) * 4);     // may wrap below zero: used only with a valid tap
+    for (int kh = 0; kh < g.KS; ++kh)
+      for (int kw = 0; kw < g.KS; ++kw)
+        if ((unsigned)(hi0 + kh) < (unsigned)g.H && (unsigned)(wi0 + kw) < (unsigned)g.W) c.mask |= 1u << (kh * g.KS + kw);
     return c;
   }
-  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int, float* v) const {
     const int T = g.KS * g.KS, q = k0 >> 5;  // wave-uniform (k0 % 32 == 0, C % 32 == 0)
     const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
-    const int c0 = cc * 32 + kin;
     const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
-    const int hi = c.hi0 + kh, wi = c.wi0 + kw;
-    const bool ok = c.base >= 0 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-    const unsigned off = ok ? (unsigned)((c.base + hi * g.W + wi) * g.C + c0) : 0u;   // < 2^31 elements: launcher check
-    const float4 t = *reinterpret_cast<const float4*>(x + off);
+    const unsigned soff = (unsigned)(((kh * g.W + kw) * g.C + cc * 32) * 4);   // scalar
+    const bool ok = (c.mask >> tap) & 1u;
+    const unsigned off = ok ? c.boff + soff : 0u;
+    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + off);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     return ok;
   }
 };
 
-// ---- dgrad A: rows = INPUT pixels, K = (kh,kw,co), gathers dy
+// ---- dgrad A: rows = INPUT pixels, K = (kh,kw,co), gathers dy  (same per-vector context as the forward gather)
 struct Im2colDgrad {
   static constexpr bool KCONTIG = true;
   static constexpr int VEC = 4;
-  struct Ctx { int base, hp, wp; };
+  struct Ctx { unsigned boff[2]; unsigned mask; };   // stride 1: boff[0] only; stride 2: tap (kh,kw) -> pixel ((hp-kh)/2, (wp-kw)/2)
   const float* dy;
   Geom g;
   int M;
   TapDiv td;
-  __device__ __forceinline__ Ctx prep(int m) const {
+  __device__ __forceinline__ Ctx prep(int m) const { return prep2(m, 0); }
+  __device__ __forceinline__ Ctx prep2(int m, int kin) const {
     Ctx c;
-    if (m >= M) { c.base = -1; c.hp = c.wp = 0; return c; }
+    c.boff[0] = c.boff[1] = 0u; c.mask = 0u;
+    if (m >= M) return c;
     const int hw = g.H * g.W;
     const int n = m / hw, r = m - n * hw;
     const int hi = r / g.W, wi = r - hi * g.W;
-    c.base = n * g.Ho * g.Wo;
-    c.hp = hi + g.pad;
-    c.wp = wi + g.pad;
+    const int hp = hi + g.pad, wp = wi + g.pad;
+    for (int kh = 0; kh < g.KS; ++kh)
+      for (int kw = 0; kw < g.KS; ++kw) {
+        int ho = hp - kh, wo = wp - kw;
+        bool ok = ho >= 0 && wo >= 0;
+        if (g.stride == 2) { ok = ok && !((ho | wo) & 1); ho >>= 1; wo >>= 1; }
+        if (ok && ho < g.Ho && wo < g.Wo) c.mask |= 1u << (kh * g.KS + kw);
+      }
+    // stride 1: pixel (hp - kh, wp - kw) = origin (hp, wp) minus the tap; stride 2: the per-tap pixel is not affine in the
+    // tap, so the origin keeps (hp, wp) and load() halves the (scalar) tap shift -- valid taps have even hp-kh / wp-kw
+    if (g.stride == 1) c.boff[0] = (unsigned)((((n * g.Ho + hp) * g.Wo + wp) * g.Co + kin) * 4);   // affine in the tap
+    else c.boff[0] = (unsigned)((((n * g.Ho) * g.Wo) * g.Co + kin) * 4);
+    c.boff[1] = (unsigned)(hp * 65536 + wp);
     return c;
   }
-  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int kin, float* v) const {
+  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int, float* v) const {
     const int T = g.KS * g.KS, q = k0 >> 5;
     const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
-    const int c0 = cc * 32 + kin;
     const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
-    const int th = c.hp - kh, tw = c.wp - kw;
-    bool ok = c.base >= 0 && th >= 0 && tw >= 0;
-    int ho = th, wo = tw;
-    if (g.stride == 2) {
-      ok = ok && !((th | tw) & 1);
-      ho >>= 1; wo >>= 1;
+    const bool ok = (c.mask >> tap) & 1u;
+    unsigned off;
+    if (g.stride == 1) {                   // one add of a scalar: pixel (hp - kh, wp - kw)
+      off = ok ? c.boff[0] + (unsigned)((cc * 32 - (kh * g.Wo + kw) * g.Co) * 4) : 0u;
+    } else {
+      const int ho = ((int)(c.boff[1] >> 16) - kh) >> 1, wo = ((int)(c.boff[1] & 0xffffu) - kw) >> 1;
+      off = ok ? c.boff[0] + (unsigned)(((ho * g.Wo + wo) * g.Co + cc * 32) * 4) : 0u;
     }
-    ok = ok && ho < g.Ho && wo < g.Wo;
-    const unsigned off = ok ? (unsigned)((c.base + ho * g.Wo + wo) * g.Co + c0) : 0u;
-    const float4 t = *reinterpret_cast<const float4*>(dy + off);
+    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dy) + off);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     return ok;
   }
@@ -193,22 +209,30 @@ struct EpiS2 {
   }
 };
 
-// packed weights [(tap, ch)][x] read in (chunk, tap, channel) K order: k = (cc*T + tap)*32 + r -> row tap*C + cc*32 + r
+// packed weights [(tap, ch)][x] read in (chunk, tap, channel) K order: k = (cc*T + tap)*32 + r -> row tap*C + cc*32 + r.
+// Per-vector context: byte offset of (row r = k_local, column x); a K tile adds the scalar (tap*C + cc*32) * ld.
+// (K % 32 == 0 for every convolution that uses this functor: a K tile is valid as a whole)
 struct ColTapRows {
   static constexpr bool KCONTIG = false;
   static constexpr int VEC = 4;
-  typedef igemm::NoCtx Ctx;
+  static constexpr bool PERVEC = true;
+  struct Ctx { unsigned boff; int ok; };
   const float* p;
   long ld;
   int X, K, C, T;
   unsigned mg_T;
-  __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
-  __device__ __forceinline__ bool load(const Ctx&, int x, int k0, int kin, float* v) const {
-    const int k = k0 + kin;
-    const bool ok = k < K && x < X;
-    const int q = k >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;
-    const unsigned off = ok ? (unsigned)((tap * C + cc * 32 + (k & 31)) * (int)ld + x) : 0u;
-    const float4 t = *reinterpret_cast<const float4*>(p + off);
+  __device__ __forceinline__ Ctx prep(int x) const { return prep2(x, 0); }
+  __device__ __forceinline__ Ctx prep2(int x, int kl) const {
+    Ctx c;
+    c.ok = x < X;
+    c.boff = c.ok ? (unsigned)((kl * (int)ld + x) * 4) : 0u;
+    return c;
+  }
+  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int, float* v) const {
+    const int q = k0 >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;         // wave-uniform
+    const bool ok = c.ok && k0 < K;
+    const unsigned off = ok ? c.boff + (unsigned)((tap * C + cc * 32) * (int)ld * 4) : 0u;
+    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + off);
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
     return ok;
   }

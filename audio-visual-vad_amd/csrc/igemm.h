@@ -136,6 +136,20 @@ struct HasPost : std::false_type {};
 template <class Op>
 struct HasPost<Op, std::void_t<decltype(&Op::post)>> : std::true_type {};
 
+// An operand functor may ask for one context PER STAGED VECTOR (static constexpr bool PERVEC = true) and build it with
+// prep2(x, k_local): everything about a vector's address that does not change from K tile to K tile -- its row / column,
+// its k position inside the tile -- is then folded into the context once per tile segment, and load() is left with one
+// add of a wave-uniform (SALU-computed) offset.  On this chip VALU time adds to fp32-MFMA time (the matrix instruction
+// runs on the vector lanes): the per-K-tile address arithmetic of the im2col gathers was ~17 % of the convolution time.
+template <class Op, class = void>
+struct HasPrep2 : std::false_type {};
+template <class Op>
+struct HasPrep2<Op, std::void_t<decltype(&Op::prep2)>> : std::true_type {};
+template <class Op, class = void>
+struct PerVec : std::false_type {};
+template <class Op>
+struct PerVec<Op, std::void_t<decltype(Op::PERVEC)>> : std::integral_constant<bool, Op::PERVEC> {};
+
 // ---------------------------------------------------------------- the kernel
 // bf16 operands (option "bf16", BASELINE config 5): the fp32 values are rounded to bf16 (RNE) on their way into LDS and
 // multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- 16x the matrix rate of the fp32-input instruction.  That
@@ -152,7 +166,7 @@ struct Stage {
   static constexpr int VEC = Op::VEC;
   static constexpr int NV = BX * BK / (NTH * VEC);
   static constexpr int LD = Op::KCONTIG ? BX + 1 : BX + 4;
-  static constexpr int NCTX = Op::KCONTIG ? NV : 1;
+  static constexpr int NCTX = (Op::KCONTIG || PerVec<Op>::value) ? NV : 1;
   static constexpr int TILE_F32 = BK * LD;                 // floats of the fp32 (k-major) image
   static constexpr int TILE_BF = BX * LDH / 2;             // floats' worth of the bf16 (x-major) image
   // thread -> (x_local, k_local) of its i-th vector
@@ -319,9 +333,19 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
     typename AOp::Ctx actx[SA::NCTX];
     typename BOp::Ctx bctx[SB::NCTX];
 #pragma unroll
-    for (int i = 0; i < SA::NCTX; ++i) { int xl, kl; SA::coord(t, i, xl, kl); actx[i] = A.prep(m0 + xl); }
+    for (int i = 0; i < SA::NCTX; ++i) {
+      int xl, kl;
+      SA::coord(t, i, xl, kl);
+      if constexpr (HasPrep2<AOp>::value) actx[i] = A.prep2(m0 + xl, kl);
+      else actx[i] = A.prep(m0 + xl);
+    }
 #pragma unroll
-    for (int i = 0; i < SB::NCTX; ++i) { int xl, kl; SB::coord(t, i, xl, kl); bctx[i] = B.prep(n0 + xl); }
+    for (int i = 0; i < SB::NCTX; ++i) {
+      int xl, kl;
+      SB::coord(t, i, xl, kl);
+      if constexpr (HasPrep2<BOp>::value) bctx[i] = B.prep2(n0 + xl, kl);
+      else bctx[i] = B.prep(n0 + xl);
+    }
 
     float sa[SA::NV][SA::VEC], sb[SB::NV][SB::VEC];
     unsigned oka = ~0u, okb = ~0u;   // bit i: staged vector i holds a real element (see OPERAND CONTRACT)
@@ -340,15 +364,15 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
       for (int i = 0; i < SA::NV; ++i) {
         int xl, kl;
         SA::coord(t, i, xl, kl);
-        if constexpr (AB) oka |= (unsigned)A.load(actx[AOp::KCONTIG ? i : 0], m0 + xl, k0, kl, sa[i]) << i;
-        else A.load(actx[AOp::KCONTIG ? i : 0], m0 + xl, k0, kl, sa[i]);
+        if constexpr (AB) oka |= (unsigned)A.load(actx[SA::NCTX > 1 ? i : 0], m0 + xl, k0, kl, sa[i]) << i;
+        else A.load(actx[SA::NCTX > 1 ? i : 0], m0 + xl, k0, kl, sa[i]);
       }
 #pragma unroll
       for (int i = 0; i < SB::NV; ++i) {
         int xl, kl;
         SB::coord(t, i, xl, kl);
-        if constexpr (BB) okb |= (unsigned)B.load(bctx[BOp::KCONTIG ? i : 0], n0 + xl, k0, kl, sb[i]) << i;
-        else B.load(bctx[BOp::KCONTIG ? i : 0], n0 + xl, k0, kl, sb[i]);
+        if constexpr (BB) okb |= (unsigned)B.load(bctx[SB::NCTX > 1 ? i : 0], n0 + xl, k0, kl, sb[i]) << i;
+        else B.load(bctx[SB::NCTX > 1 ? i : 0], n0 + xl, k0, kl, sb[i]);
       }
     };
 
