@@ -267,7 +267,9 @@ __global__ void __launch_bounds__(256)
 //  (the flat form spends ~1900 VALU cycles per tile on 64-bit per-lane address arithmetic, and on this chip VALU time adds
 //  to fp32-MFMA time: the matrix instruction runs on the vector lanes).  Both timed within 3 % of this kernel at the bench
 //  and C2 shapes: its ~36 us per bench-shape layer are the SUM of the access pattern's streaming time (20 us alone) and the
-//  matrix time (15 us alone), and neither occupancy nor fewer VALU instructions made the two overlap.)
+//  matrix time (15 us alone), and neither occupancy nor fewer VALU instructions made the two overlap.  Nor did pinning the
+//  next tile's 48 loads in front of this tile's MFMAs with sched_barrier -- hipcc sinks them below the first 32 MFMAs
+//  otherwise -- which timed 3 % slower.)
 
 // ------------------------------------------------------------------ fused MFMA backward of a residual block (R = D = 32, fw = 2)
 // (A)  dz[d][t] = (z[d][t] > 0) * sum_r W_dense[r][d] * dS[r][t]            -- 16 MFMAs per 32-sample tile
