@@ -60,62 +60,85 @@ __global__ void lstm_gates_fwd(float* __restrict__ G, float* __restrict__ Cs, fl
 //  skinny treatment for the backward product dh = dG W_hh (64 columns x a K-split per workgroup, slabs summed by the gate
 //  kernel): equal to the stream-K GEMM within 0.1 ms -- both stream all of W_hh every step.)
 typedef float f32x4v __attribute__((ext_vector_type(4)));
+// blockIdx.y selects a group of BG = min(B, 64) sequences, blockIdx.x a run of 4*UB hidden units.  At B = 256 (BASELINE
+// config 1) the step is bound by L2 traffic: every workgroup re-reads h_{t-1} of its 64 sequences (256 KB) next to its
+// weight slab (64 KB per 4 units), 328 MB per step with UB = 1 -- 72 us.  UB = 4 shares one read of h between 16 units:
+// 131 MB per step.
+template <int UB>
 __global__ void __launch_bounds__(1024)
     lstm_step_fwd_mfma(float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ y, const float* __restrict__ w_hh,
                        const int* __restrict__ lengths, int B, int T, int H, int t) {
-  __shared__ f32x4v part[16][64];
+  __shared__ f32x4v part[UB][16][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int nb = B >> 4, KS = 16 / nb;
+  const int BG = B < 64 ? B : 64;                            // sequences per workgroup
+  const int nb = BG >> 4, KS = 16 / nb;
   const int wb = wave % nb, ks = wave / nb;
   const int i = lane & 15, q = lane >> 4;
   const int blk = blockIdx.x;
-  const int b = wb * 16 + i;                                 // this lane's sequence (B operand column / D column)
+  const int b = blockIdx.y * BG + wb * 16 + i;               // this lane's sequence (B operand column / D column)
   const int kspan = H / KS;                                  // host guarantees H % (16*KS) == 0
-  const float* wrow = w_hh + (long)((i & 3) * H + 4 * blk + (i >> 2)) * H + ks * kspan + 4 * q;   // A row i = 4*u + gate
+  // A row i = 4*u + gate of unit-quad ub: W_hh row gate*H + 4*(blk*UB + ub) + u
+  const float* wrow = w_hh + (long)((i & 3) * H + 4 * blk * UB + (i >> 2)) * H + ks * kspan + 4 * q;
   const float* hrow = y + ((long)b * T + (t - 1)) * H + ks * kspan + 4 * q;
-  f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+  f32x4v acc[UB];
+#pragma unroll
+  for (int ub = 0; ub < UB; ++ub) acc[ub] = f32x4v{0.f, 0.f, 0.f, 0.f};
   const int nk = kspan >> 4;
   for (int k0 = 0; k0 < nk; k0 += 8) {
-    float4 a[8], h[8];
+    float4 h[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int kk = (k0 + u < nk) ? k0 + u : nk - 1;       // clamped (nk % 8 != 0 shapes); masked below
-      a[u] = *reinterpret_cast<const float4*>(wrow + 16 * kk);
       h[u] = *reinterpret_cast<const float4*>(hrow + 16 * kk);
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      if (k0 + u < nk) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, h[u].x, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, h[u].y, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, h[u].z, acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, h[u].w, acc, 0, 0, 0);
+    for (int ub = 0; ub < UB; ++ub) {
+      float4 a[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int kk = (k0 + u < nk) ? k0 + u : nk - 1;
+        a[u] = *reinterpret_cast<const float4*>(wrow + (long)ub * 4 * H + 16 * kk);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (k0 + u < nk) {
+          acc[ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].x, h[u].x, acc[ub], 0, 0, 0);
+          acc[ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].y, h[u].y, acc[ub], 0, 0, 0);
+          acc[ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].z, h[u].z, acc[ub], 0, 0, 0);
+          acc[ub] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u].w, h[u].w, acc[ub], 0, 0, 0);
+        }
       }
     }
   }
-  part[wave][lane] = acc;
+#pragma unroll
+  for (int ub = 0; ub < UB; ++ub) part[ub][wave][lane] = acc[ub];
   __syncthreads();
   if (ks != 0) return;
-  for (int s2 = 1; s2 < KS; ++s2) {
-    const f32x4v p = part[s2 * nb + wb][lane];
-    acc[0] += p[0]; acc[1] += p[1]; acc[2] += p[2]; acc[3] += p[3];
+  const bool live = t < lengths[b];
+#pragma unroll
+  for (int ub = 0; ub < UB; ++ub) {
+    f32x4v r = acc[ub];
+    for (int s2 = 1; s2 < KS; ++s2) {
+      const f32x4v p = part[ub][s2 * nb + wb][lane];
+      r[0] += p[0]; r[1] += p[1]; r[2] += p[2]; r[3] += p[3];
+    }
+    // r[gate] = recurrent part of the gate of unit j for sequence b
+    const int j = 4 * (blk * UB + ub) + q;
+    float* g = G + ((long)b * T + t) * 4 * H;
+    const long o = ((long)b * T + t) * H + j;
+    if (!live) {
+      g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f; g[3 * H + j] = 0.f;
+      Cs[o] = 0.f; y[o] = 0.f;
+      continue;
+    }
+    const float ig = sigmoidf_(g[j] + r[0]), fg = sigmoidf_(g[H + j] + r[1]), gg = tanhf(g[2 * H + j] + r[2]),
+                og = sigmoidf_(g[3 * H + j] + r[3]);
+    const float cp = Cs[o - H];
+    const float c = fg * cp + ig * gg;
+    g[j] = ig; g[H + j] = fg; g[2 * H + j] = gg; g[3 * H + j] = og;
+    Cs[o] = c;
+    y[o] = og * tanhf(c);
   }
-  // acc[r] = recurrent part of gate r of unit 4*blk + q for sequence b
-  const int j = 4 * blk + q;
-  float* g = G + ((long)b * T + t) * 4 * H;
-  const long o = ((long)b * T + t) * H + j;
-  if (t >= lengths[b]) {
-    g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f; g[3 * H + j] = 0.f;
-    Cs[o] = 0.f; y[o] = 0.f;
-    return;
-  }
-  const float ig = sigmoidf_(g[j] + acc[0]), fg = sigmoidf_(g[H + j] + acc[1]), gg = tanhf(g[2 * H + j] + acc[2]),
-              og = sigmoidf_(g[3 * H + j] + acc[3]);
-  const float cp = Cs[o - H];
-  const float c = fg * cp + ig * gg;
-  g[j] = ig; g[H + j] = fg; g[2 * H + j] = gg; g[3 * H + j] = og;
-  Cs[o] = c;
-  y[o] = og * tanhf(c);
 }
 
 // in: activated gates in G, dy[b][t], DH (recurrent dh from step t+1, consumed and zeroed), DC (dc from t+1)
@@ -159,21 +182,39 @@ __global__ void fill0(float* p, long n) {
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
 }
 
-// out[c] += sum_r X[r][c]  (and out2 if given)
+// out[c] += sum_r X[r][c]  (and out2 if given): bias gradients over all (sequence, step) rows.  Two deterministic stages:
+// (column quad, row chunk) workgroups leave partial sums, a second kernel adds the chunks in order.  (The first version
+// walked all rows with cols/64 workgroups: 1.4 ms per call at the C2 shape, 15 360 rows x 4096 columns.)
+constexpr int CS_CHUNKS = 64;
 __global__ void __launch_bounds__(256)
-    colsum_acc(const float* __restrict__ X, int rows, int cols, float* __restrict__ out, float* __restrict__ out2) {
-  __shared__ float sm[256];
-  const int t = threadIdx.x, c = blockIdx.x * 64 + (t & 63), rl = t >> 6;
-  float s = 0.f;
+    colsum_stage1(const float* __restrict__ X, int rows, int cols, float* __restrict__ part) {
+  __shared__ float4 sm[4][64];
+  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + q) * 4;
+  const int per = (rows + CS_CHUNKS - 1) / CS_CHUNKS;
+  const int r0 = blockIdx.y * per, r1 = min(rows, r0 + per);
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c < cols)
-    for (int r = rl; r < rows; r += 4) s += X[(long)r * cols + c];
-  sm[t] = s;
+    for (int r = r0 + rl; r < r1; r += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(X + (long)r * cols + c);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+  sm[rl][q] = s;
   __syncthreads();
   if (rl == 0 && c < cols) {
-    const float v = sm[t] + sm[t + 64] + sm[t + 128] + sm[t + 192];
-    out[c] += v;
-    if (out2) out2[c] += v;
+    float4 t = sm[0][q];
+#pragma unroll
+    for (int k = 1; k < 4; ++k) { t.x += sm[k][q].x; t.y += sm[k][q].y; t.z += sm[k][q].z; t.w += sm[k][q].w; }
+    *reinterpret_cast<float4*>(part + (long)blockIdx.y * cols + c) = t;
   }
+}
+__global__ void colsum_stage2(const float* __restrict__ part, int cols, float* __restrict__ out, float* __restrict__ out2) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float s = 0.f;
+  for (int k = 0; k < CS_CHUNKS; ++k) s += part[(long)k * cols + c];
+  out[c] += s;
+  if (out2) out2[c] += s;
 }
 
 struct Ws {
@@ -228,11 +269,16 @@ extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const flo
   avvad_gemm_desc gd = gemm_desc(B * T, 4 * H, In, In, In, 4 * H, 0, 1, 0, 1);
   if ((rc = avvad_gemm_impl(x, w_ih, w.bias, w.G, &gd, s, w.slab))) return rc;
   const int split = pick_split(B, 4 * H, H);
-  const bool fused_step = (B == 16 || B == 32 || B == 64 || B == 128 || B == 256) && (H % (16 * (256 / B)) == 0) &&
+  // sequences are handled in groups of BG = min(B, 64) (blockIdx.y); a group's 16 waves are BG/16 sequence blocks x KS K-slices
+  const int BG = B < 64 ? B : 64;
+  const bool fused_step = (B == 16 || B == 32 || (B % 64 == 0 && B <= 65535 * 64)) && (H % (16 * (256 / BG)) == 0) &&
                           !avvad_tune().lstm_no_fused_step;
   for (int t = 0; t < T; ++t) {
     if (t > 0 && fused_step) {
-      hipLaunchKernelGGL(lstm_step_fwd_mfma, dim3(H / 4), dim3(1024), 0, s, w.G, w.Cs, y, w_hh, d->lengths, B, T, H, t);
+      if (B >= 128 && H % 16 == 0)        // many sequences: one read of h_{t-1} serves 16 hidden units
+        hipLaunchKernelGGL(lstm_step_fwd_mfma<4>, dim3(H / 16, B / BG), dim3(1024), 0, s, w.G, w.Cs, y, w_hh, d->lengths, B, T, H, t);
+      else
+        hipLaunchKernelGGL(lstm_step_fwd_mfma<1>, dim3(H / 4, B / BG), dim3(1024), 0, s, w.G, w.Cs, y, w_hh, d->lengths, B, T, H, t);
       continue;
     }
     if (t > 0) {
@@ -280,9 +326,11 @@ extern "C" int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const flo
     avvad_gemm_desc g3 = gemm_desc(4 * H, H, R, 4 * H, H, H, 1, 0, 1, pick_split(4 * H, H, R));
     if ((rc = avvad_gemm_impl(w.G, w.Ys, nullptr, dw_hh, &g3, s, w.slab))) return rc;
   }
-  if (db_ih || db_hh)
-    hipLaunchKernelGGL(colsum_acc, dim3(cdiv(4 * H, 64)), dim3(256), 0, s, w.G, R, 4 * H, db_ih ? db_ih : db_hh,
+  if (db_ih || db_hh) {          // (4H % 4 == 0; the engine scratch is free here and holds the CS_CHUNKS x 4H partial sums)
+    hipLaunchKernelGGL(colsum_stage1, dim3(cdiv(4 * H, 256), CS_CHUNKS), dim3(256), 0, s, w.G, R, 4 * H, w.slab);
+    hipLaunchKernelGGL(colsum_stage2, dim3(cdiv(4 * H, 256)), dim3(256), 0, s, w.slab, 4 * H, db_ih ? db_ih : db_hh,
                        (db_ih && db_hh) ? db_hh : (float*)nullptr);
+  }
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

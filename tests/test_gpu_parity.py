@@ -239,6 +239,34 @@ def test_lstm_full_size():
     _report("lstm 2x1024 In=768", y, ref, 1e-4)
 
 
+@pytest.mark.parametrize("B,H", [(16, 256), (32, 128), (64, 64), (128, 128), (192, 64), (256, 1024)])
+def test_lstm_fused_step_sequence_groups(B, H):
+    """The fused recurrent step (MFMA, one launch per time step) handles the batch in groups of min(B, 64) sequences:
+    BASELINE config 1's 256 sequences are four groups.  Ragged lengths, forward + backward against the oracle's time loop."""
+    from avvad import ops
+    from oracle import head
+    import torch.nn as nn
+    torch.manual_seed(B + H)
+    In, Tn = 40, 5 if H < 1024 else 3
+    lstm = nn.LSTM(In, H, 1)
+    x = torch.randn(B, Tn, In)
+    lens = [int(v) for v in torch.randint(1, Tn + 1, (B,))]
+    lens[0] = Tn
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in lstm.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    ref = head.lstm_stack(xr, lens, sd, "", 1)
+    Gd = torch.randn(B, Tn, H)
+    (ref * Gd).sum().backward()
+    lstm = lstm.to(DEV)
+    xg = x.to(DEV).requires_grad_(True)
+    y = ops.lstm_stack(xg, lens, lstm)
+    _report("lstm B=%d H=%d forward" % (B, H), y, ref, 1e-4)
+    (y * Gd.to(DEV)).sum().backward()
+    _report_grad("lstm B=%d d/dx" % B, xg.grad, xr.grad)
+    for k, p in lstm.named_parameters():
+        _report_grad("lstm B=%d d/d%s" % (B, k), p.grad, sd[k].grad)
+
+
 def test_bce_and_metrics():
     from packages.models.utils import binary_cross_entropy, f1_loss
     g = load_golden("misc")
