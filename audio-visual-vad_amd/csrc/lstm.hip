@@ -58,7 +58,10 @@ __global__ void lstm_gates_fwd(float* __restrict__ G, float* __restrict__ Cs, fl
 //  correct, but 0.4 ms/step SLOWER end to end: the per-step release/acquire fences that carry h_t across XCDs write back
 //  and invalidate the whole L2, which costs more than re-streaming W_hh from the Infinity Cache.  Also tried: the same
 //  skinny treatment for the backward product dh = dG W_hh (64 columns x a K-split per workgroup, slabs summed by the gate
-//  kernel): equal to the stream-K GEMM within 0.1 ms -- both stream all of W_hh every step.)
+//  kernel): equal to the stream-K GEMM within 0.1 ms -- both stream all of W_hh every step.  Round 2 tried a fused backward
+//  step in this kernel's image -- W_hh transposed once, workgroup = 16 units x 64 sequences, dh in the accumulators, gate
+//  backward of step t-1 in registers: correct, one launch instead of three, but only H/16 = 64 workgroups each streaming
+//  1.25 MB of gate gradients: 1.3 ms/step SLOWER at the bench shape, 2.5 ms at C2.)
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 // blockIdx.y selects a group of BG = min(B, 64) sequences, blockIdx.x a run of 4*UB hidden units.  At B = 256 (BASELINE
 // config 1) the step is bound by L2 traffic: every workgroup re-reads h_{t-1} of its 64 sequences (256 KB) next to its
