@@ -36,6 +36,8 @@ struct AvvadTune {
   int no_tall;              // 128x64 tiles instead of 256x64 for the 64-channel convolutions
   int wn_no_fused_tail;     // unfused encoder tail backward
   int wn_no_fused_wgrad;    // unfused encoder block backward (dz, weight gradients as separate kernels)
+  int wn_flat;               // residual-block forward: 0 by size, 1 flat dword kernel, 2 dword buffer kernel, 3 wide (dwordx4) buffer kernel
+  int wn_grid;               // tuning aid: workgroup cap of the wide residual-block kernels (0 = default)
   int wn_bwd_t;             // alternate block backward: transposed products (no LDS transposes), 250 registers, 2 waves / SIMD
   int bf16;                 // bf16-input MFMA (fp32 accumulate) for the convolutions and dense GEMMs: BASELINE config 5's arithmetic
   int max_cus;              // cap on the CUs a persistent grid occupies (0 = all 256): leaves room for RCCL kernels
@@ -51,12 +53,17 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
-// max(x, 0) as ONE instruction: v_med3_f32 x, 0, +inf.  fmaxf() costs two (hipcc first canonicalises a possible
-// signalling NaN with v_max_f32 x, x, x), and on this chip the fp32 MFMA runs on the vector ALUs' own lanes, so a VALU
-// instruction per matrix operand is not free.  (An inline-asm v_max_f32 is NOT an option: the compiler's hazard recogniser
-// does not see a VALU write inside an asm statement and leaves out the wait states an MFMA needs before it reads that
-// register -- the first version did exactly that and computed garbage, run-to-run different.)
-__device__ __forceinline__ float relu1(float x) { return __builtin_amdgcn_fmed3f(x, 0.f, __builtin_huge_valf()); }
+// max(x, 0) as ONE instruction: v_max_i32 on the float's bits (a negative float is a negative integer; -0 -> +0; a
+// positive NaN stays a NaN).  fmaxf() costs two (hipcc first canonicalises a possible signalling NaN with v_max_f32 x, x),
+// and so does v_med3_f32 x, 0, +inf, which it folds back into the same pair; on this chip the fp32 MFMA runs on the vector
+// ALUs' own lanes, so a VALU instruction per matrix operand is not free (measured: ~4 matrix-pipe cycles each).  (An
+// inline-asm v_max_f32 is NOT an option: the compiler's hazard recogniser does not see a VALU write inside an asm statement
+// and leaves out the wait states an MFMA needs before it reads that register -- the first version did exactly that and
+// computed garbage, run-to-run different.)
+__device__ __forceinline__ float relu1(float x) {
+  const int v = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, v > 0 ? v : 0);
+}
 // row of D register r for lane-half h
 __device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 

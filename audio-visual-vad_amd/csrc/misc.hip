@@ -21,13 +21,15 @@ const OptName kOpts[] = {
     {"wn_no_fused_tail", "AVVAD_WN_NO_FUSED_TAIL", &AvvadTune::wn_no_fused_tail},
     {"wn_no_fused_wgrad", "AVVAD_WN_NO_FUSED_WGRAD", &AvvadTune::wn_no_fused_wgrad},
     {"wn_bwd_t", "AVVAD_WN_BWD_T", &AvvadTune::wn_bwd_t},
+    {"wn_flat", "AVVAD_WN_FLAT", &AvvadTune::wn_flat},
+    {"wn_grid", "AVVAD_WN_GRID", &AvvadTune::wn_grid},
     {"bf16", "AVVAD_BF16", &AvvadTune::bf16},
     {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
 };
 int parse_opt(const char* name, const char* v) {
   if (!strcmp(name, "igemm_variant")) return v[0] == 'd' ? 0 : (v[0] == 's' ? 1 : (v[0] == 'w' ? 2 : atoi(v)));
   if (!strcmp(name, "no_streamk")) return v[0] == 'a' ? 1 : (v[0] >= '0' && v[0] <= '9' && !v[1] ? 10 + (v[0] - '0') : atoi(v));
-  if (!strcmp(name, "max_cus")) return atoi(v);
+  if (!strcmp(name, "max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid")) return atoi(v);
   return (v[0] && strcmp(v, "0")) ? 1 : 0;
 }
 }  // namespace

@@ -262,7 +262,255 @@ __global__ void __launch_bounds__(256)
 }
 
 
-// (Round 2 tried two other shapes of this kernel -- tools/lab/mem_lab.py holds the measurements: a 3-waves-per-SIMD form
+// BUFFER-ADDRESSED form of the same block (the default; option "wn_flat" selects the kernel above).  On this chip the fp32
+// MFMA runs on the vector lanes: every VALU instruction costs ~4 matrix-pipe cycles whatever the occupancy (tools/lab/
+// mfvar_lab.py: a wave's MFMA chain at 0.90 of the pipe with ~50 VALU per tile, 0.71 with ~220, the same at 1, 2 and 3
+// waves/SIMD).  The flat kernel above carries 718 VALU instructions per 48 MFMAs -- 139 64-bit address adds, 96 v_max (two
+// per ReLU), 85 validity selects -- i.e. as many vector cycles as matrix cycles.  Here a tile's addressing is wave-uniform:
+//   * one buffer descriptor per tensor and tile (SALU), ONE per-lane byte offset, the row in the instruction's scalar offset;
+//   * lanes past the end of a sequence carry an out-of-range offset: their loads return 0 and their stores are dropped by
+//     the bounds check, so no select touches the data;
+//   * ReLU is one integer max (relu1);
+//   * the cross-tile prefetch alternates between two register sets instead of copying.
+constexpr int BUF_OOB = (int)0x80000000;      // beyond any descriptor's num_records (< 2^31 by the launch precondition)
+constexpr int BUF_WORD3 = 0x00020000;         // raw buffer, 32-bit data format
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t brsrc(const float* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, BUF_WORD3);
+}
+
+template <int MODE>
+__global__ void __launch_bounds__(256)
+    wn_block_fwd_buf(const float* __restrict__ s_in, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
+                     const float* __restrict__ w_dense, const float* __restrict__ b_dense, float* __restrict__ s_out,
+                     float* __restrict__ z_out, int B, int Lin, int dil) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const int ntiles = B * tiles_per_seq;
+  const int wave0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6));
+  const int nwaves = (int)((gridDim.x * blockDim.x) >> 6);
+  __shared__ float wl[32 * 65 + 32 * 33 + 64];
+  float wd[32];   // W_dil[d = li][c = s][tap = lh]
+  float we[16];   // W_dense[r = li][d = row(r', lh)]
+  const float* bzl = wl + 3136 + 4 * lh;
+  const float* bsl = wl + 3168 + 4 * lh;
+  const int rowL = Lin * 4, rowO = Lo * 4;     // bytes per row of the input / output tensors
+
+  // request tile `tile`'s 48 values (clamped to the last tile when there is none: the values are then never used)
+  auto issue = [&](int tile, float (&xn)[32], float (&rn)[16]) {
+    const int tl = tile < ntiles ? tile : ntiles - 1;
+    const int b = tl / tiles_per_seq;
+    const int t = (tl - b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lo;
+    const __amdgpu_buffer_rsrc_t rx = brsrc(s_in + (long)b * 32 * Lin, 32 * rowL);
+    const int offx = ok ? (t + lh * dil) * 4 : BUF_OOB;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) xn[c] = bload(rx, offx, c * rowL);
+    if (MODE <= 1) {
+      const int offr = ok ? (t + dil) * 4 + 4 * lh * rowL : BUF_OOB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rn[r] = bload(rx, offr, mfma32_row(r, 0) * rowL);
+    }
+  };
+  auto compute = [&](int tile, const float (&x)[32], const float (&rv)[16]) {
+    const int b = tile / tiles_per_seq;
+    const int t = (tile - b * tiles_per_seq) * 32 + li;
+    const int offo = t < Lo ? t * 4 + 4 * lh * rowO : BUF_OOB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bzl[mfma32_row(r, 0)];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = mfma32(wd[s], relu1(x[s]), acc);
+    if (MODE >= 1) {
+      const __amdgpu_buffer_rsrc_t rz = brsrc(z_out + (long)b * 32 * Lo, 32 * rowO);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bstore(acc[r], rz, offo, mfma32_row(r, 0) * rowO);
+    }
+    if (MODE <= 1) {
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = bsl[mfma32_row(r, 0)] + rv[r];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2 = mfma32(we[r], relu1(acc[r]), acc2);
+      const __amdgpu_buffer_rsrc_t ro = brsrc(s_out + (long)b * 32 * Lo, 32 * rowO);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bstore(acc2[r], ro, offo, mfma32_row(r, 0) * rowO);
+    }
+  };
+  // XCD-aware walk: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so XCD x takes the contiguous
+  // eighth [lo, hi) of the tiles and its waves sweep it side by side -- the second tap and the residual of a tile (the
+  // same plane, `dil` samples later) are then lines that a neighbouring wave of the SAME XCD fetched a moment ago.  Dealt
+  // out by raw wave id, tile j's neighbours j + dil/32 sat in other XCDs and every plane crossed the fabric ~1.7 times.
+  int first = wave0, last = ntiles, stride = nwaves;
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, nbx = gridDim.x >> 3;
+    first = (int)((long)ntiles * xcd / 8) + ((blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6));
+    last = (int)((long)ntiles * (xcd + 1) / 8);
+    stride = nbx * 4;
+  }
+  first = __builtin_amdgcn_readfirstlane(first);
+  float xa[32], ra[16], xb[32], rb[16];
+  if (first < last) issue(first, xa, ra);
+  // the first tile's requests are on their way while the block's weights make their own round trip (global -> LDS ->
+  // registers): at the bench shape a launch lasts ~37 us and each of the two latencies is ~2 us of it
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  for (int i = threadIdx.x; i < 1024; i += 256) wl[2080 + (i >> 5) * 33 + (i & 31)] = w_dense[i];
+  if (threadIdx.x < 32) {
+    wl[3136 + threadIdx.x] = b_dil ? b_dil[threadIdx.x] : 0.f;
+    wl[3168 + threadIdx.x] = b_dense ? b_dense[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int s = 0; s < 32; ++s) wd[s] = wl[li * 65 + s * 2 + lh];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) we[r] = wl[2080 + li * 33 + mfma32_row(r, lh)];
+  for (int tile = first; tile < last; tile += 2 * stride) {
+    issue(tile + stride, xb, rb);          // in flight during the MFMAs below (a tile past `last` is fetched, never used)
+    compute(tile, xa, ra);
+    if (tile + stride >= last) break;
+    issue(tile + 2 * stride, xa, ra);
+    compute(tile + stride, xb, rb);
+  }
+}
+
+// WIDE form (the default for planes of >= 128 samples): the same block with 16-byte memory instructions.  The dword
+// kernels above are ISSUE-bound in the memory pipe -- 64 one-dword wave-instructions per 32-sample tile keep the CU's
+// address unit busier (~1000 cycles) than the tile's 48 MFMAs keep the matrix pipe (768), and a wave that is stuck issuing
+// its loads issues no MFMAs behind them either -- so here one wave owns a 128-sample SUPER-tile as four interleaved
+// sub-tiles (sub-tile j = samples t0 + 4n + j: columns are independent, so any set of 32 columns is a valid MFMA tile):
+// lane n holds 4 consecutive samples, every load / store is a dwordx4 (rows start at any sample: 4-byte aligned 16-byte
+// accesses), and the instruction count per sample drops 4x.  The weights come from LDS per MFMA group (one ds_read feeds
+// four MFMAs), the residual is fetched (an L1/L2 hit: the tap-1 lanes just read those lines) into the x registers once the
+// dilated product is done.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4v bload4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore4(f4v v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, v), r, voff, soff, 0);
+}
+
+#ifndef W4_RELU
+#define W4_RELU relu1
+#endif
+__global__ void __launch_bounds__(256, 2)
+    wn_block_fwd_w4(const float* __restrict__ s_in, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
+                    const float* __restrict__ w_dense, const float* __restrict__ b_dense, float* __restrict__ s_out, int B,
+                    int Lin, int dil) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 127) >> 7;
+  const int ntiles = B * tiles_per_seq;
+  __shared__ float wl[32 * 65 + 32 * 33 + 64];
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  for (int i = threadIdx.x; i < 1024; i += 256) wl[2080 + (i >> 5) * 33 + (i & 31)] = w_dense[i];
+  if (threadIdx.x < 32) {
+    wl[3136 + threadIdx.x] = b_dil ? b_dil[threadIdx.x] : 0.f;
+    wl[3168 + threadIdx.x] = b_dense ? b_dense[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  const float* wdl = wl + li * 65 + lh;            // W_dil[d = li][c = s][tap = lh] at wdl[2 s]
+  const float* wel = wl + 2080 + li * 33 + 4 * lh; // W_dense[r = li][d = row(r', lh)] at wel[row(r', 0)]
+  const float* bzl = wl + 3136 + 4 * lh;
+  const float* bsl = wl + 3168 + 4 * lh;
+  const int rowL = Lin * 4, rowO = Lo * 4;
+
+  // XCD-aware walk (see wn_block_fwd_buf)
+  int first = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6), last = ntiles, stride = (int)((gridDim.x * blockDim.x) >> 6);
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7, nbx = gridDim.x >> 3;
+    first = (int)((long)ntiles * xcd / 8) + ((blockIdx.x >> 3) * 4 + (int)(threadIdx.x >> 6));
+    last = (int)((long)ntiles * (xcd + 1) / 8);
+    stride = nbx * 4;
+  }
+  first = __builtin_amdgcn_readfirstlane(first);
+  for (int tile = first; tile < last; tile += stride) {
+    const int b = tile / tiles_per_seq;
+    const int t0 = (tile - b * tiles_per_seq) * 128;
+    const int t = t0 + 4 * li;                     // this lane's first sample
+    const __amdgpu_buffer_rsrc_t rx = brsrc(s_in + (long)b * 32 * Lin, 32 * rowL);
+    const __amdgpu_buffer_rsrc_t ro = brsrc(s_out + (long)b * 32 * Lo, 32 * rowO);
+    // samples past the end of a row read into the next row (or return 0 past the slab): garbage columns, never stored
+    const int offx = (t + lh * dil) * 4;
+    f4v x[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = bload4(rx, offx, c * rowL);
+    // all 32 requests go out BEFORE the first MFMA (left alone, hipcc hoists the weights into 48 registers, has too few left
+    // for x and re-fetches it two loads at a time between the MFMAs: a memory round trip per four MFMAs).  The weight
+    // pointers are laundered per tile so that their LDS reads stay inside the loop.
+    __builtin_amdgcn_sched_barrier(0);
+    const float* wd_t = wdl;
+    const float* we_t = wel;
+#ifndef W4_NO_LAUNDER
+    asm volatile("" : "+v"(wd_t), "+v"(we_t));
+#endif
+    f32x16 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = bzl[mfma32_row(r, 0)];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const float w = wd_t[2 * s];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] = mfma32(w, W4_RELU(x[s][j]), acc[j]);
+    }
+    // residual rows (same plane, `dil` samples later: the lines the tap-1 half just read), into registers x no longer needs
+    const int offr = (t + dil) * 4 + 4 * lh * rowL;
+    f4v rv[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) rv[r] = bload4(rx, offr, mfma32_row(r, 0) * rowL);
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[j][r] = bsl[mfma32_row(r, 0)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float w = we_t[mfma32_row(r, 0)];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc2[j] = mfma32(w, W4_RELU(acc[j][r]), acc2[j]);
+    }
+    const int offo = t * 4 + 4 * lh * rowO;
+    if (t0 + 128 <= Lo) {
+      // All 16 sums first (in place of rv), THEN the 16 stores, nothing writing their data registers behind them.
+      // gfx950 hazard the compiler does not know: a buffer_store_dwordx4 whose soffset is an SGPR still reads its data
+      // registers a moment after issue, exactly like the immediate-soffset form hipcc pads with a wait state.  With the sum
+      // of row r+1 computed into the registers of row r's store right behind it, 16 lanes of the store's first dword were
+      // the NEXT row's value -- only with two waves per SIMD (the other wave's traffic delays the read), only rows whose
+      // store had an SGPR soffset and a successor: r = 1..14 (tests: test_wavenet_block_kernel_forms_agree).
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const f4v o = {acc2[0][r] + rv[r][0], acc2[1][r] + rv[r][1], acc2[2][r] + rv[r][2], acc2[3][r] + rv[r][3]};
+        rv[r] = o;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bstore4(rv[r], ro, offo, mfma32_row(r, 0) * rowO);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_nop 1");
+    } else {          // last super-tile of a sequence: element-wise, out-of-range samples dropped by the bounds check
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int oj = t + j < Lo ? offo + 4 * j : BUF_OOB;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bstore(acc2[j][r] + rv[r][j], ro, oj, mfma32_row(r, 0) * rowO);
+      }
+    }
+  }
+}
+
+// (Round 2 also tried two other shapes of the FLAT kernel -- tools/lab/mem_lab.py holds the measurements: a 3-waves-per-SIMD form
 //  with the weight fragments read from LDS and no cross-tile prefetch, and one with wave-uniform scalar/buffer addressing
 //  (the flat form spends ~1900 VALU cycles per tile on 64-bit per-lane address arithmetic, and on this chip VALU time adds
 //  to fp32-MFMA time: the matrix instruction runs on the vector lanes).  Both timed within 3 % of this kernel at the bench
@@ -1101,6 +1349,43 @@ static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
 }
 
 static inline bool mfma_shape(const avvad_wavenet_desc* d) { return d->R == 32 && d->D == 32 && d->fw == 2; }
+// forward of one residual block, MFMA shape: wide kernel when the plane has >= 128 output samples, else the dword forms
+static void launch_block_fwd(const float* s_in, const float* wd, const float* bd, const float* we, const float* be, float* s_out,
+                             int B, int Lin, int dil, hipStream_t s);
+// the buffer-addressed block kernels index a sequence's [32][L] slab with 31-bit byte offsets and count tiles in an int
+static inline bool buf_ok(int B, int Lin) {
+  return avvad_tune().wn_flat != 1 && (long)Lin * 32 * 4 + 4096 < (1L << 31) && (long)B * cdiv(Lin, 32) < (1L << 31);
+}
+// option "wn_flat": 0 by size (wide dwordx4 kernel for big planes, else the dword buffer kernel), 1 flat dword kernel,
+// 2 dword buffer kernel, 3 wide kernel
+static void launch_block_fwd(const float* s_in, const float* wd, const float* bd, const float* we, const float* be, float* s_out,
+                             int B, int Lin, int dil, hipStream_t s) {
+  const int Lo = Lin - dil;
+  // wide kernel for long planes (C2's one-second chunks: 290 vs 363 us per layer); at the bench shape (64 planes of ~6000
+  // samples, 3008 super-tiles) the dword kernel's finer tiles balance better and the two time the same (37-38 us).  The
+  // choice depends on the plane LENGTH only: the two forms round the residual add differently (last bit), and a sequence's
+  // result must not depend on how many others share its batch.
+  if (buf_ok(B, Lin) && (avvad_tune().wn_flat == 0 || avvad_tune().wn_flat == 3) && Lo >= 128 &&
+      (Lo >= 8192 || avvad_tune().wn_flat == 3)) {
+    const long ntiles = (long)B * cdiv(Lo, 128);
+    long blocks = (ntiles + 3) / 4;
+    const long cap = avvad_tune().wn_grid > 0 ? avvad_tune().wn_grid : 1024;
+    if (blocks > cap) blocks = cap;
+    blocks = (blocks + 7) / 8 * 8;                  // whole XCD groups (surplus waves find no tile)
+    hipLaunchKernelGGL(wn_block_fwd_w4, dim3((int)blocks), dim3(256), 0, s, s_in, wd, bd, we, be, s_out, B, Lin, dil);
+    return;
+  }
+  const long ntiles = (long)B * cdiv(Lo, 32);
+  long blocks = (ntiles + 3) / 4;
+  if (blocks > 512) blocks = 512;    // 2 waves per SIMD resident; each wave walks >= 5 tiles at the bench shape
+  if (avvad_tune().wn_grid > 0 && blocks > avvad_tune().wn_grid) blocks = avvad_tune().wn_grid;
+  if (buf_ok(B, Lin))
+    hipLaunchKernelGGL(wn_block_fwd_buf<0>, dim3((int)blocks), dim3(256), 0, s, s_in, wd, bd, we, be, s_out, (float*)nullptr, B, Lin,
+                       dil);
+  else
+    hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, s, s_in, wd, bd, we, be, s_out, (float*)nullptr, B, Lin,
+                       dil);
+}
 
 // dw[co][ci][k] += sum_{b,t} dy[b][co][t] * f(x[b][ci][t + k*dil])  for every tap, on the engine
 static int wgrad_conv1d(const float* dy, const float* x, float* dw, int B, int Cout, int Cin, int Lout, int Lin, int fw,
@@ -1149,12 +1434,8 @@ extern "C" int avvad_wavenet_fwd(const float* wave, const avvad_wavenet_params* 
     const float* bd = d->use_bias ? prm->dil_b_h[i] : nullptr;
     const float* be = d->use_bias ? prm->dense_b_h[i] : nullptr;
     if (mfma_shape(d)) {
-      const long ntiles = (long)B * cdiv(p.L[i + 1], 32);
-      long blocks = (ntiles + 3) / 4;
-      if (blocks > 512) blocks = 512;    // 2 waves per SIMD resident; each wave walks >= 5 tiles at the bench shape
       // z (pre-ReLU dilation output) is NOT kept: backward rebuilds it from s_i inside its fused kernel, bit-identically
-      hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, s, ws + p.s[i], prm->dil_w_h[i], bd,
-                         prm->dense_w_h[i], be, ws + p.s[i + 1], (float*)nullptr, B, p.L[i], dil);
+      launch_block_fwd(ws + p.s[i], prm->dil_w_h[i], bd, prm->dense_w_h[i], be, ws + p.s[i + 1], B, p.L[i], dil, s);
     } else {
       float* z = ws + p.z;
       hipLaunchKernelGGL(conv1d_fwd_generic, dim3(grid1((long)B * D * p.L[i + 1])), dim3(256), 0, s, ws + p.s[i],
@@ -1188,11 +1469,7 @@ extern "C" int avvad_wavenet_block_fwd(const float* s_in, const float* w_dil, co
                                        const float* b_dense, float* s_out, int B, int Lin, int dil, avvad_stream_t sv) {
   AVVAD_ENTER();
   if (!s_in || !w_dil || !w_dense || !s_out || B <= 0 || dil < 1 || Lin - dil < 1) return AVVAD_EINVAL;
-  const long ntiles = (long)B * cdiv(Lin - dil, 32);
-  long blocks = (ntiles + 3) / 4;
-  if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(wn_block_fwd_mfma<0>, dim3((int)blocks), dim3(256), 0, (hipStream_t)sv, s_in, w_dil, b_dil, w_dense, b_dense,
-                     s_out, (float*)nullptr, B, Lin, dil);
+  launch_block_fwd(s_in, w_dil, b_dil, w_dense, b_dense, s_out, B, Lin, dil, (hipStream_t)sv);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

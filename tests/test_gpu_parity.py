@@ -902,6 +902,42 @@ def test_input_standardisation_in_the_train_loop():
 
 
 # ------------------------------------------------------------------------------------------ BASELINE-size properties
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Lin,dil,grid", [(3, 700, 1, 0), (2, 1200, 64, 8), (5, 2300, 512, 8), (4, 1027, 16, 16), (16, 16000, 64, 0),
+                                             (256, 16000, 512, 0), (256, 15999, 1, 0), (64, 14977, 256, 0)])
+def test_wavenet_block_kernel_forms_agree(B, Lin, dil, grid, lib_options):
+    """One residual block through avvad_wavenet_block_fwd in its three forms (option wn_flat: 1 flat dword addressing,
+    2 buffer dword, 3 wide dwordx4) against the plain torch fp32 statement of the block (wavenet_autoencoder.py:78-86);
+    a small workgroup cap (wn_grid) makes every wave walk several tiles, tails included."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from avvad import _lib as L_
+    lib = L_.lib()
+    torch.manual_seed(B * 1000 + dil)
+    s_in = torch.randn(B, 32, Lin, device=DEV)
+    wd, bd = torch.randn(32, 32, 2, device=DEV) * 0.2, torch.randn(32, device=DEV) * 0.1
+    we, be = torch.randn(32, 32, 1, device=DEV) * 0.2, torch.randn(32, device=DEV) * 0.1
+    big = B * Lin > 1 << 20          # BASELINE configs[1] planes: the flat-addressed kernel (form 1) is the reference
+    if not big:
+        ref = F.conv1d(F.relu(F.conv1d(F.relu(s_in.double()), wd.double(), bd.double(), dilation=dil)), we.double(), be.double())
+        ref = (ref + s_in.double()[:, :, dil:]).float()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    outs = {}
+    for form in (1, 2, 3):
+        lib_options("wn_flat", form)
+        lib_options("wn_grid", grid)
+        out = torch.full((B, 32, Lin - dil), float("nan"), device=DEV)
+        L_.check(lib.avvad_wavenet_block_fwd(L_.ptr(s_in), L_.ptr(wd), L_.ptr(bd), L_.ptr(we), L_.ptr(be), L_.ptr(out), B, Lin,
+                                             dil, st), "avvad_wavenet_block_fwd")
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all(), "form %d left samples unwritten" % form
+        if big and form == 1:
+            ref = out
+        assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), "form %d" % form
+        outs[form] = out
+    assert torch.equal(outs[1], outs[2])          # same arithmetic, different addressing
+
+
 def _max_rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 

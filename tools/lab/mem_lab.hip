@@ -272,3 +272,191 @@ extern "C" __global__ void __launch_bounds__(256) clk_mfma_rand(unsigned long lo
 extern "C" void launch_clk_rand(unsigned long long* out, float* sink, const float* rnd, int iters, int blocks, hipStream_t s) {
   hipLaunchKernelGGL(clk_mfma_rand, dim3(blocks), dim3(256), 0, s, out, sink, rnd, iters);
 }
+
+// ---- in-kernel clock of the forward block's work mix (loads + MFMA chain + stores), stamped around the whole tile loop
+template <int LOADS, int MFMA>
+__global__ void __launch_bounds__(256, 3) fwdclk(const float* __restrict__ s_in, float* __restrict__ s_out, unsigned long long* __restrict__ stamp, int B, int Lin, int dil) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil, tps = (Lo + 31) >> 5;
+  const long ntiles = (long)B * tps;
+  const long w0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nw = ((long)gridDim.x * blockDim.x) >> 6;
+  __shared__ float wl[32 * 65 + 32 * 33 + 64];
+  for (int i = threadIdx.x; i < 32 * 65 + 32 * 33 + 64; i += 256) wl[i] = 0.001f * (i % 17);
+  __syncthreads();
+  const float* wdp = wl + li * 65 + lh;
+  const float* wep = wl + 2080 + li * 33;
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  for (long tile = w0; tile < ntiles; tile += nw) {
+    const int b = (int)(tile / tps), t = (int)(tile - (long)b * tps) * 32 + li;
+    const bool ok = t < Lo;
+    const int tcl = ok ? t : 0;
+    float x[32], rv[16];
+    const float* xp = s_in + (long)b * 32 * Lin + tcl + lh * dil;
+    if (LOADS) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) x[c] = xp[(long)c * Lin];
+      const float* rp = s_in + (long)b * 32 * Lin + tcl + dil;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = rp[(long)mrow(r, lh) * Lin];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) x[c] = (float)(t + c) * 0.37f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (MFMA) {
+#pragma unroll
+      for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wdp[2 * s], ok ? fmaxf(x[s], 0.f) : 0.f, acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = x[2 * r] + x[2 * r + 1];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = (ok ? rv[r] : 0.f);
+    if (MFMA) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wep[mrow(r, lh)], fmaxf(acc[r], 0.f), acc2, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] += acc[r];
+    }
+    float* op = s_out + (long)b * 32 * Lo + t;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      if (ok && (LOADS || acc2[r] == 12345.678f)) op[(long)mrow(r, lh) * Lo] = acc2[r];
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    stamp[4 * w] = c1 - c0; stamp[4 * w + 1] = r1 - r0; stamp[4 * w + 2] = r0;
+    stamp[4 * w + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+  }
+}
+#define LAUNCHC(n, L, M) extern "C" void launch_##n(const float* a, float* b, unsigned long long* st, int B, int Lin, int dil, int blocks, hipStream_t s) { hipLaunchKernelGGL((fwdclk<L, M>), dim3(blocks), dim3(256), 0, s, a, b, st, B, Lin, dil); }
+LAUNCHC(clk_full, 1, 1) LAUNCHC(clk_mfmaonly, 0, 1) LAUNCHC(clk_memonly, 1, 0)
+
+// ---- what keeps the block's MFMA chain below the pipe's rate: variants of the MFMA-only body
+// LDSW: weights from LDS (1) or registers (0); RELU: max+select on the B operand; TWO: two tiles' chains interleaved
+template <int LDSW, int RELU, int TWO, int XGEN>
+__global__ void __launch_bounds__(256, 2) mfvar(float* __restrict__ s_out, int ntiles_per_wave) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  __shared__ float wl[32 * 65 + 32 * 33 + 64];
+  for (int i = threadIdx.x; i < 32 * 65 + 32 * 33 + 64; i += 256) wl[i] = 0.001f * (i % 17);
+  __syncthreads();
+  const float* wdp = wl + li * 65 + lh;
+  const float* wep = wl + 2080 + li * 33;
+  float wreg[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) wreg[i] = wdp[i];
+  float keep = 0.f;
+  for (int it = 0; it < ntiles_per_wave; it += (TWO ? 2 : 1)) {
+    const int t = it * 32 + li;
+    const bool ok = (t & 1023) != 1023;
+    float x[32], x2[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) { x[c] = XGEN ? (float)(t + c) * 0.37f : keep + (float)c; x2[c] = XGEN ? (float)(t + c) * 0.11f : keep - (float)c; }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x16 acc, acc2, bcc, bcc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; bcc[r] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const float a = LDSW ? wdp[2 * s] : wreg[s & 7];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RELU ? (ok ? fmaxf(x[s], 0.f) : 0.f) : x[s], acc, 0, 0, 0);
+      if (TWO) bcc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RELU ? (ok ? fmaxf(x2[s], 0.f) : 0.f) : x2[s], bcc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc2[r] = 0.f; bcc2[r] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float a = LDSW ? wep[mrow(r, lh)] : wreg[r & 7];
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RELU ? fmaxf(acc[r], 0.f) : acc[r], acc2, 0, 0, 0);
+      if (TWO) bcc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, RELU ? fmaxf(bcc[r], 0.f) : bcc[r], bcc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) keep += acc2[r] + (TWO ? bcc2[r] : 0.f);
+  }
+  if (keep == 12345.678f) s_out[threadIdx.x] = keep;
+}
+#define LAUNCHV(n, A, B, C, D) extern "C" void launch_##n(float* b, int ntw, int blocks, hipStream_t s) { hipLaunchKernelGGL((mfvar<A, B, C, D>), dim3(blocks), dim3(256), 0, s, b, ntw); }
+LAUNCHV(v_base, 1, 1, 0, 1) LAUNCHV(v_regw, 0, 1, 0, 1) LAUNCHV(v_regw_norelu, 0, 0, 0, 1) LAUNCHV(v_two, 1, 1, 1, 1) LAUNCHV(v_pure, 0, 0, 0, 0)
+LAUNCHV(v_lds_norelu, 1, 0, 0, 1) LAUNCHV(v_two_pure, 0, 0, 1, 0)
+
+// ---- the same work mix with buffer addressing: one descriptor per tensor and tile (SALU), ONE per-lane byte offset, the row
+// offset in the instruction's scalar offset -> no per-load VALU address math; masked lanes carry an out-of-range offset (loads
+// return 0, stores are dropped) -> no validity selects; ReLU as a one-instruction integer max
+__device__ __forceinline__ float relu_i(float x) { const int v = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, v > 0 ? v : 0); }
+template <int LOADS, int MFMA>
+__global__ void __launch_bounds__(256, 2) fwdclk2(const float* __restrict__ s_in, float* __restrict__ s_out, unsigned long long* __restrict__ stamp, int B, int Lin, int dil) {
+  const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil, tps = (Lo + 31) >> 5;
+  const int ntiles = B * tps;
+  const int w0 = __builtin_amdgcn_readfirstlane((int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6)), nw = (int)((gridDim.x * blockDim.x) >> 6);
+  __shared__ float wl[32 * 65 + 32 * 33 + 64];
+  for (int i = threadIdx.x; i < 32 * 65 + 32 * 33 + 64; i += 256) wl[i] = 0.001f * (i % 17);
+  __syncthreads();
+  float wd[32], we[16];
+#pragma unroll
+  for (int s = 0; s < 32; ++s) wd[s] = wl[li * 65 + lh + 2 * s];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) we[r] = wl[2080 + li * 33 + mrow(r, lh)];
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+  const int rowL = Lin * 4, rowO = Lo * 4;   // bytes per row (uniform)
+  for (int tile = w0; tile < ntiles; tile += nw) {
+    const int b = tile / tps, t0 = (tile - b * tps) * 32;          // scalar
+    const int t = t0 + li;
+    const bool ok = t < Lo;
+    const int offx = ok ? (t + lh * dil) * 4 : (int)0x80000000;
+    const int offr = ok ? (t + dil) * 4 + 4 * lh * rowL : (int)0x80000000;
+    const int offo = ok ? t * 4 + 4 * lh * rowO : (int)0x80000000;
+    __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(s_in + (long)b * 32 * Lin), 0, 32 * rowL, 0x00020000);
+    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(s_out + (long)b * 32 * Lo), 0, 32 * rowO, 0x00020000);
+    float x[32], rv[16];
+    if (LOADS) {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) x[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, offx, c * rowL, 0));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, offr, mrow(r, 0) * rowL, 0));
+    } else {
+#pragma unroll
+      for (int c = 0; c < 32; ++c) x[c] = (float)(t + c) * 0.37f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = 0.f;
+    }
+    f32x16 acc, acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    if (MFMA) {
+#pragma unroll
+      for (int s = 0; s < 32; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wd[s], relu_i(x[s]), acc, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = x[2 * r] + x[2 * r + 1];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = rv[r];
+    if (MFMA) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(we[r], relu_i(acc[r]), acc2, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] += acc[r];
+    }
+    if (LOADS || acc2[0] == 12345.678f) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, acc2[r]), ro, offo, mrow(r, 0) * rowO, 0);
+    }
+  }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+  if (lane == 0) {
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    stamp[4 * w] = c1 - c0; stamp[4 * w + 1] = r1 - r0; stamp[4 * w + 2] = r0;
+    stamp[4 * w + 3] = ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32) | (unsigned)__builtin_amdgcn_s_getreg(63492);
+  }
+}
+#define LAUNCHC2(n, L, M) extern "C" void launch_##n(const float* a, float* b, unsigned long long* st, int B, int Lin, int dil, int blocks, hipStream_t s) { hipLaunchKernelGGL((fwdclk2<L, M>), dim3(blocks), dim3(256), 0, s, a, b, st, B, Lin, dil); }
+LAUNCHC2(clk2_full, 1, 1) LAUNCHC2(clk2_mfmaonly, 0, 1) LAUNCHC2(clk2_memonly, 1, 0)
