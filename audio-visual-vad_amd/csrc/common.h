@@ -36,6 +36,7 @@ struct AvvadTune {
   int no_tall;              // 128x64 tiles instead of 256x64 for the 64-channel convolutions
   int wn_no_fused_tail;     // unfused encoder tail backward
   int wn_no_fused_wgrad;    // unfused encoder block backward (dz, weight gradients as separate kernels)
+  int no_buf;                // convolution gathers with flat addressing + validity selects (the form operands >= 2 GiB use)
   int wn_flat;               // residual-block forward: 0 by size, 1 flat dword kernel, 2 dword buffer kernel, 3 wide (dwordx4) buffer kernel
   int wn_grid;               // tuning aid: workgroup cap of the wide residual-block kernels (0 = default)
   int wn_bwd_t;             // alternate block backward: transposed products (no LDS transposes), 250 registers, 2 waves / SIMD
@@ -63,6 +64,33 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 __device__ __forceinline__ float relu1(float x) {
   const int v = __builtin_bit_cast(int, x);
   return __builtin_bit_cast(float, v > 0 ? v : 0);
+}
+// ---- buffer addressing.  A tile's addressing as (descriptor in SGPRs, ONE 32-bit per-lane byte offset, scalar offset in
+// the instruction): no 64-bit per-lane address arithmetic, and a lane that must not touch memory carries BUF_OOB -- the
+// bounds check returns 0 to its load and drops its store, so no select ever touches the data.  num_records is < 2^31 for
+// every descriptor built here (launch preconditions), so an offset with bit 31 set is out of range for all of them.
+// HAZARD (gfx950, unknown to hipcc 7.2): buffer_store_dwordx4 with an SGPR soffset reads its data registers a moment after
+// issue, like the immediate-soffset form the compiler pads; do not write those registers in the next instructions.
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
+constexpr int BUF_OOB = (int)0x80000000;
+constexpr int BUF_WORD3 = 0x00020000;         // raw buffer, 32-bit data format
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t brsrc(const float* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, BUF_WORD3);
+}
+// descriptor over "everything within 2 GiB of p": for operands whose real extent the host has checked to be < 2^31 bytes
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t brsrc2g(const float* p) { return brsrc(p, (int)0x80000000); }
+__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
+}
+__device__ __forceinline__ f4v bload4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void bstore4(f4v v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, v), r, voff, soff, 0);
 }
 // row of D register r for lane-half h
 __device__ __forceinline__ constexpr int mfma32_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }

@@ -14,10 +14,33 @@
 // which time an XCD's 64 resident workgroups have streamed > 4 MiB through its L2: rocprof showed the forward
 // kernel fetching 7.5x its input from beyond L2 (profiles/r01_pmc_fetch_size_per_kernel.csv).  Weights stay in
 // the plain packed layouts; the B functors remap rows.
+//
+// BUF.  Every gather functor comes in two addressing forms.  BUF = true (operands < 2 GiB, checked by the launcher): the
+// fetch is a buffer load against a descriptor over the operand, an element that is padding / out of range carries the
+// out-of-range offset BUF_OOB and comes back as 0 from the bounds check, and load() returns nothing -- the engine then
+// compiles no validity selects into the staging at all (3 % of the forward kernel's time, VALU instructions that add to
+// fp32-MFMA time on this chip) and the address is a 32-bit register instead of a 64-bit add per load.  BUF = false: flat
+// loads from a clamped address + a validity bit, zero-filled at the LDS store (operands of 2 GiB and more).
 #pragma once
 #include "igemm.h"
 
 namespace convop {
+
+// 16 bytes at byte offset `off` of operand p (BUF: off == BUF_OOB -> zeros; flat: the caller clamped off to a valid address)
+template <bool BUF>
+__device__ __forceinline__ void fetch4(const float* p, unsigned off, float* v) {
+  if constexpr (BUF) {
+    const f4v t = bload4(brsrc2g(p), (int)off, 0);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  } else {
+    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+  }
+}
+template <bool BUF> struct LoadRet { typedef bool type; };
+template <> struct LoadRet<true> { typedef void type; };
+#define CONVOP_RETURN(ok) do { if constexpr (!BUF) return ok; else return; } while (0)
+constexpr unsigned INVALID_OFF(bool buf) { return buf ? 0x80000000u : 0u; }
 
 struct Geom {
   int N, H, W, C, Ho, Wo, Co, KS, stride, pad;
@@ -39,6 +62,7 @@ static inline TapDiv tap_div(int T, int KS) { return TapDiv{div_magic((unsigned)
 // Context per staged vector: the BYTE offset of (window origin, channel kin) and one validity bit per tap.  A K tile is
 // one tap of one 32-channel chunk (wave-uniform), so load() adds a scalar tap offset and tests one bit.
 // (host: the activation tensor is < 4 GiB -- 32-bit byte offsets -- and KS*KS <= 32)
+template <bool BUF>
 struct Im2colFwd {
   static constexpr bool KCONTIG = true;
   static constexpr int VEC = 4;
@@ -62,20 +86,19 @@ struct Im2colFwd {
         if ((unsigned)(hi0 + kh) < (unsigned)g.H && (unsigned)(wi0 + kw) < (unsigned)g.W) c.mask |= 1u << (kh * g.KS + kw);
     return c;
   }
-  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int, float* v) const {
+  __device__ __forceinline__ typename LoadRet<BUF>::type load(const Ctx& c, int, int k0, int, float* v) const {
     const int T = g.KS * g.KS, q = k0 >> 5;  // wave-uniform (k0 % 32 == 0, C % 32 == 0)
     const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
     const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
     const unsigned soff = (unsigned)(((kh * g.W + kw) * g.C + cc * 32) * 4);   // scalar
     const bool ok = (c.mask >> tap) & 1u;
-    const unsigned off = ok ? c.boff + soff : 0u;
-    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(x) + off);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    return ok;
+    fetch4<BUF>(x, ok ? c.boff + soff : INVALID_OFF(BUF), v);
+    CONVOP_RETURN(ok);
   }
 };
 
 // ---- dgrad A: rows = INPUT pixels, K = (kh,kw,co), gathers dy  (same per-vector context as the forward gather)
+template <bool BUF>
 struct Im2colDgrad {
   static constexpr bool KCONTIG = true;
   static constexpr int VEC = 4;
@@ -107,21 +130,20 @@ struct Im2colDgrad {
     c.boff[1] = (unsigned)(hp * 65536 + wp);
     return c;
   }
-  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int, float* v) const {
+  __device__ __forceinline__ typename LoadRet<BUF>::type load(const Ctx& c, int, int k0, int, float* v) const {
     const int T = g.KS * g.KS, q = k0 >> 5;
     const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
     const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
     const bool ok = (c.mask >> tap) & 1u;
     unsigned off;
     if (g.stride == 1) {                   // one add of a scalar: pixel (hp - kh, wp - kw)
-      off = ok ? c.boff[0] + (unsigned)((cc * 32 - (kh * g.Wo + kw) * g.Co) * 4) : 0u;
+      off = ok ? c.boff[0] + (unsigned)((cc * 32 - (kh * g.Wo + kw) * g.Co) * 4) : INVALID_OFF(BUF);
     } else {
       const int ho = ((int)(c.boff[1] >> 16) - kh) >> 1, wo = ((int)(c.boff[1] & 0xffffu) - kw) >> 1;
-      off = ok ? c.boff[0] + (unsigned)(((ho * g.Wo + wo) * g.Co + cc * 32) * 4) : 0u;
+      off = ok ? c.boff[0] + (unsigned)(((ho * g.Wo + wo) * g.Co + cc * 32) * 4) : INVALID_OFF(BUF);
     }
-    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(dy) + off);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    return ok;
+    fetch4<BUF>(dy, off, v);
+    CONVOP_RETURN(ok);
   }
 };
 
@@ -137,6 +159,7 @@ struct S2Class {
   int oh, ow;           // ho = i + oh - a, wo = j + ow - b for tap (kh0 + 2a, kw0 + 2b)
   unsigned mg_ntap, mg_nkw;   // div_magic(nkh*nkw), div_magic(nkw)
 };
+template <bool BUF>
 struct Im2colDgradS2 {
   static constexpr bool KCONTIG = true;
   static constexpr int VEC = 4;
@@ -155,21 +178,20 @@ struct Im2colDgradS2 {
     x.base = n * g.Ho * g.Wo;
     return x;
   }
-  __device__ __forceinline__ bool load(const Ctx& x, int, int k0, int kin, float* v) const {
+  __device__ __forceinline__ typename LoadRet<BUF>::type load(const Ctx& x, int, int k0, int kin, float* v) const {
     const int ntap = c.nkh * c.nkw, q = k0 >> 5;
     const int cc = fast_div(q, c.mg_ntap), seg = q - cc * ntap;
     const int c0 = cc * 32 + kin;
     const int a = fast_div(seg, c.mg_nkw), b = seg - a * c.nkw;
     const int ho = x.i + c.oh - a, wo = x.j + c.ow - b;
     const bool ok = x.base >= 0 && (unsigned)ho < (unsigned)g.Ho && (unsigned)wo < (unsigned)g.Wo;
-    const unsigned off = ok ? (unsigned)((x.base + ho * g.Wo + wo) * g.Co + c0) : 0u;
-    const float4 t = *reinterpret_cast<const float4*>(dy + off);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    return ok;
+    fetch4<BUF>(dy, ok ? (unsigned)((x.base + ho * g.Wo + wo) * g.Co + c0) * 4u : INVALID_OFF(BUF), v);
+    CONVOP_RETURN(ok);
   }
 };
 // weight rows of the live taps in (chunk, tap, channel) K order:
 //   k = (cc*ntap + tap)*32 + r  ->  row rowbase[tap] + cc*32 + r
+template <bool BUF>
 struct ColSegRows {
   static constexpr bool KCONTIG = false;
   static constexpr int VEC = 4;
@@ -180,15 +202,13 @@ struct ColSegRows {
   int rowbase[4];
   unsigned mg_ntap;
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
-  __device__ __forceinline__ bool load(const Ctx&, int x, int k0, int kin, float* v) const {
+  __device__ __forceinline__ typename LoadRet<BUF>::type load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
     const bool ok = k < K && x < X;
     const int q = k >> 5, cc = fast_div(q, mg_ntap), seg = (q - cc * ntap) & 3;
     const int rb = seg == 0 ? rowbase[0] : (seg == 1 ? rowbase[1] : (seg == 2 ? rowbase[2] : rowbase[3]));  // no scratch array
-    const unsigned off = ok ? (unsigned)((rb + cc * 32 + (k & 31)) * (int)ld + x) : 0u;
-    const float4 t = *reinterpret_cast<const float4*>(p + off);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    return ok;
+    fetch4<BUF>(p, ok ? (unsigned)((rb + cc * 32 + (k & 31)) * (int)ld + x) * 4u : INVALID_OFF(BUF), v);
+    CONVOP_RETURN(ok);
   }
 };
 // epilogue: class-local row m -> input pixel (n, 2i+ph, 2j+pw); always accumulating (the caller zero-fills; plain RMW:
@@ -212,6 +232,7 @@ struct EpiS2 {
 // packed weights [(tap, ch)][x] read in (chunk, tap, channel) K order: k = (cc*T + tap)*32 + r -> row tap*C + cc*32 + r.
 // Per-vector context: byte offset of (row r = k_local, column x); a K tile adds the scalar (tap*C + cc*32) * ld.
 // (K % 32 == 0 for every convolution that uses this functor: a K tile is valid as a whole)
+template <bool BUF>
 struct ColTapRows {
   static constexpr bool KCONTIG = false;
   static constexpr int VEC = 4;
@@ -228,13 +249,11 @@ struct ColTapRows {
     c.boff = c.ok ? (unsigned)((kl * (int)ld + x) * 4) : 0u;
     return c;
   }
-  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int, float* v) const {
+  __device__ __forceinline__ typename LoadRet<BUF>::type load(const Ctx& c, int, int k0, int, float* v) const {
     const int q = k0 >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;         // wave-uniform
     const bool ok = c.ok && k0 < K;
-    const unsigned off = ok ? c.boff + (unsigned)((tap * C + cc * 32) * (int)ld * 4) : 0u;
-    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(p) + off);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    return ok;
+    fetch4<BUF>(p, ok ? c.boff + (unsigned)((tap * C + cc * 32) * (int)ld * 4) : INVALID_OFF(BUF), v);
+    CONVOP_RETURN(ok);
   }
 };
 // wgrad epilogue: GEMM row m' = (cc*T + tap)*32 + r (chunk-major, see WgradX) -> packed row tap*C + cc*32 + r
@@ -254,6 +273,7 @@ struct EpiWgrad {
 
 // ---- wgrad A: A[m][k = output pixel] = x[n, ho*s-p+kh, wo*s-p+kw, c] with m = (cc*T + tap)*32 + r, c = cc*32 + r:
 // a 128-row M tile is 4 taps of one 32-channel chunk, so the taps' overlapping pixel reads share L1/L2 lines
+template <bool BUF>
 struct WgradX {
   static constexpr bool KCONTIG = false;
   static constexpr int VEC = 4;
@@ -272,17 +292,15 @@ struct WgradX {
     c.kw = tap - c.kh * g.KS;
     return c;
   }
-  __device__ __forceinline__ bool load(const Ctx& c, int, int k0, int kin, float* v) const {
+  __device__ __forceinline__ typename LoadRet<BUF>::type load(const Ctx& c, int, int k0, int kin, float* v) const {
     const int k = k0 + kin;
     const int hw = g.Ho * g.Wo;
     const int n = fast_div(k, mg_hw), r = k - n * hw;
     const int ho = fast_div(r, mg_wo), wo = r - ho * g.Wo;
     const int hi = ho * g.stride - g.pad + c.kh, wi = wo * g.stride - g.pad + c.kw;
     const bool ok = c.kh >= 0 && k < K && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
-    const unsigned off = ok ? (unsigned)(((n * g.H + hi) * g.W + wi) * g.C + c.c) : 0u;
-    const float4 t = *reinterpret_cast<const float4*>(x + off);
-    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    return ok;
+    fetch4<BUF>(x, ok ? (unsigned)(((n * g.H + hi) * g.W + wi) * g.C + c.c) * 4u : INVALID_OFF(BUF), v);
+    CONVOP_RETURN(ok);
   }
 };
 
@@ -340,5 +358,7 @@ struct StemWgradX {  // A[m = (kh,kw)][k = output pixel]
     if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) v[0] = x[(n * g.H + hi) * g.W + wi];
   }
 };
+
+#undef CONVOP_RETURN
 
 }  // namespace convop

@@ -86,8 +86,8 @@ struct RowSegK {
   __device__ __forceinline__ float post(float v) const { return relu ? fmaxf(v, 0.f) : v; }
 };
 
-// element (k, x) = p[k*ld + x]
-template <int V>
+// element (k, x) = p[k*ld + x]      (BUF: buffer-addressed fetch, see conv_ops.h -- the operand is < 2 GiB, V == 4)
+template <int V, bool BUF = false>
 struct ColPlain {
   static constexpr bool KCONTIG = false;
   static constexpr int VEC = V;
@@ -96,17 +96,23 @@ struct ColPlain {
   long ld;
   int X, K, relu;
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
-  __device__ __forceinline__ bool load(const Ctx&, int x, int k0, int kin, float* v) const {
+  __device__ __forceinline__ typename std::conditional<BUF, void, bool>::type load(const Ctx&, int x, int k0, int kin, float* v) const {
     const int k = k0 + kin;
     const bool ok = k < K && x < X;  // V==4: X % 4 == 0 and 16-byte aligned rows are launch preconditions
-    const long off = ok ? (long)k * ld + x : 0;
-    if (V == 4) {
-      const float4 t = *reinterpret_cast<const float4*>(p + off);
-      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    if constexpr (BUF) {
+      static_assert(V == 4, "buffer form: 16-byte fetches");
+      const f4v t = bload4(brsrc2g(p), ok ? (int)(((unsigned)k * (unsigned)ld + (unsigned)x) * 4u) : BUF_OOB, 0);
+      v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
     } else {
-      v[0] = p[off];
+      const long off = ok ? (long)k * ld + x : 0;
+      if (V == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p + off);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      } else {
+        v[0] = p[off];
+      }
+      return ok;
     }
-    return ok;
   }
   __device__ __forceinline__ float post(float v) const { return relu ? fmaxf(v, 0.f) : v; }
 };
@@ -187,7 +193,11 @@ struct Stage {
       for (int j = 0; j < VEC; ++j) {
         float v = st0[i][j];
         if constexpr (HasPost<Op>::value) v = op.post(v);
+#ifdef AVVAD_ABL_NOSEL
+        st[i][j] = v;
+#else
         st[i][j] = ((okmask >> i) & 1u) ? v : 0.f;
+#endif
       }
 #pragma unroll
     for (int i = 0; i < NV; ++i) {

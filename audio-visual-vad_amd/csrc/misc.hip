@@ -21,6 +21,7 @@ const OptName kOpts[] = {
     {"wn_no_fused_tail", "AVVAD_WN_NO_FUSED_TAIL", &AvvadTune::wn_no_fused_tail},
     {"wn_no_fused_wgrad", "AVVAD_WN_NO_FUSED_WGRAD", &AvvadTune::wn_no_fused_wgrad},
     {"wn_bwd_t", "AVVAD_WN_BWD_T", &AvvadTune::wn_bwd_t},
+    {"no_buf", "AVVAD_NO_BUF", &AvvadTune::no_buf},
     {"wn_flat", "AVVAD_WN_FLAT", &AvvadTune::wn_flat},
     {"wn_grid", "AVVAD_WN_GRID", &AvvadTune::wn_grid},
     {"bf16", "AVVAD_BF16", &AvvadTune::bf16},

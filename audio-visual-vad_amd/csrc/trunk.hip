@@ -338,7 +338,10 @@ static inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4
 
 // ------------------------------------------------------------------ conv launchers
 static inline bool fits_u31(long n) { return n >= 0 && n < (1L << 31); }
-static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab) {
+// operands below 2 GiB take the buffer-addressed gathers (conv_ops.h "BUF")
+static inline bool fits_buf(long n_floats) { return n_floats >= 0 && n_floats < (1L << 29) - 64; }
+template <bool BUF>
+static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab) {
   const int M = g.N * g.Ho * g.Wo, K = g.KS * g.KS * g.C;
   igemm::EpiStore e{y, g.Co, nullptr, 0};
   if (g.C == 1) {
@@ -356,13 +359,18 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
   if (g.C % 32 || g.Co % 4) return AVVAD_EINVAL;
   if (!fits_u31((long)g.N * g.H * g.W * g.C) || !fits_u31((long)K * g.Co)) return AVVAD_EINVAL;   // 32-bit gather offsets
   const int T = g.KS * g.KS;
-  convop::ColTapRows b{wf, g.Co, g.Co, K, g.C, T, convop::div_magic(T)};
-  convop::Im2colFwd a{x, g, M, convop::tap_div(T, g.KS)};
+  convop::ColTapRows<BUF> b{wf, g.Co, g.Co, K, g.C, T, convop::div_magic(T)};
+  convop::Im2colFwd<BUF> a{x, g, M, convop::tap_div(T, g.KS)};
   if (g.Co <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s, slab) : igemm::launch<256, 64>(a, b, e, M, g.Co, K, 1, s, slab);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s, slab);
 }
+static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab) {
+  const bool buf = fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.KS * g.KS * g.C * g.Co) && !avvad_tune().no_buf;
+  return buf ? conv_fwd_t<true>(x, wf, y, g, s, slab) : conv_fwd_t<false>(x, wf, y, g, s, slab);
+}
 // dx (+)= dgrad
-static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
+template <bool BUF>
+static int conv_dgrad_t(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
   const int M = g.N * g.H * g.W, K = g.KS * g.KS * g.Co;
   if (g.Co % 32 || g.C % 4) return AVVAD_EINVAL;
   if (!fits_u31((long)g.N * g.Ho * g.Wo * g.Co) || !fits_u31((long)K * g.C)) return AVVAD_EINVAL;   // 32-bit gather offsets
@@ -382,8 +390,8 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
         if (Mc <= 0 || ntap <= 0) continue;
         if (ntap > 4) return AVVAD_EINVAL;
         c.mg_ntap = convop::div_magic(ntap); c.mg_nkw = convop::div_magic(c.nkw);
-        convop::Im2colDgradS2 a{dy, g, c, Mc};
-        convop::ColSegRows b{wd, g.C, g.C, ntap * g.Co, ntap, {0, 0, 0, 0}, convop::div_magic(ntap)};
+        convop::Im2colDgradS2<BUF> a{dy, g, c, Mc};
+        convop::ColSegRows<BUF> b{wd, g.C, g.C, ntap * g.Co, ntap, {0, 0, 0, 0}, convop::div_magic(ntap)};
         for (int ia = 0; ia < c.nkh; ++ia)
           for (int ib = 0; ib < c.nkw; ++ib)
             b.rowbase[ia * c.nkw + ib] = ((c.kh0 + 2 * ia) * g.KS + (c.kw0 + 2 * ib)) * g.Co;
@@ -398,15 +406,20 @@ static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g
   }
   igemm::EpiStore e{dx, g.C, nullptr, accumulate ? 1 : 0};
   const int T = g.KS * g.KS;
-  convop::ColTapRows b{wd, g.C, g.C, K, g.Co, T, convop::div_magic(T)};
-  convop::Im2colDgrad a{dy, g, M, convop::tap_div(T, g.KS)};
+  convop::ColTapRows<BUF> b{wd, g.C, g.C, K, g.Co, T, convop::div_magic(T)};
+  convop::Im2colDgrad<BUF> a{dy, g, M, convop::tap_div(T, g.KS)};
   if (g.C <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.C, K, 1, s, slab) : igemm::launch<256, 64>(a, b, e, M, g.C, K, 1, s, slab);
   return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s, slab);
 }
+static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
+  const bool buf = fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && fits_buf((long)g.KS * g.KS * g.C * g.Co) && !avvad_tune().no_buf;
+  return buf ? conv_dgrad_t<true>(dy, wd, dx, g, accumulate, s, slab) : conv_dgrad_t<false>(dy, wd, dx, g, accumulate, s, slab);
+}
 // pk[(kh,kw,c)][co] = wgrad (overwritten; tiles split along K are combined by the engine's fix-up kernel, in a fixed order)
-static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s, float* slab) {
+template <bool BUF>
+static int conv_wgrad_t(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s, float* slab) {
   const int M = g.KS * g.KS * g.C, K = g.N * g.Ho * g.Wo;
-  igemm::ColPlain<4> b{dy, g.Co, g.Co, K, 0};
+  igemm::ColPlain<4, BUF> b{dy, g.Co, g.Co, K, 0};
   const int ktiles = cdiv(K, igemm::BK);
   if (g.C == 1) {
     igemm::EpiStore e{pk, g.Co, nullptr, 0};
@@ -418,12 +431,16 @@ static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g,
   convop::EpiWgrad e{pk, g.Co, nullptr, 0, 1, g.C, g.KS * g.KS, convop::div_magic(g.KS * g.KS)};
   if ((unsigned long)(K + igemm::BK) * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
   if (!fits_u31((long)g.N * g.H * g.W * g.C)) return AVVAD_EINVAL;                                              // 32-bit gather offsets
-  convop::WgradX a{x, g, M, K, convop::div_magic(g.Ho * g.Wo), convop::div_magic(g.Wo)};
+  convop::WgradX<BUF> a{x, g, M, K, convop::div_magic(g.Ho * g.Wo), convop::div_magic(g.Wo)};
   const bool small = g.Co <= 64;
   const int nb = cdiv(M, 128) * cdiv(g.Co, small ? 64 : 128);
   int split = cdiv(1024, nb); if (split > ktiles) split = ktiles;
   if (small) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, split, s, slab);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, split, s, slab);
+}
+static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s, float* slab) {
+  const bool buf = g.C > 1 && fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && !avvad_tune().no_buf;
+  return buf ? conv_wgrad_t<true>(x, dy, pk, g, s, slab) : conv_wgrad_t<false>(x, dy, pk, g, s, slab);
 }
 
 struct StatCtx { double* part; int nchunk; long rows_per_chunk; };

@@ -272,18 +272,6 @@ __global__ void __launch_bounds__(256)
 //     the bounds check, so no select touches the data;
 //   * ReLU is one integer max (relu1);
 //   * the cross-tile prefetch alternates between two register sets instead of copying.
-constexpr int BUF_OOB = (int)0x80000000;      // beyond any descriptor's num_records (< 2^31 by the launch precondition)
-constexpr int BUF_WORD3 = 0x00020000;         // raw buffer, 32-bit data format
-__device__ __forceinline__ float bload(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bstore(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, voff, soff, 0);
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t brsrc(const float* p, int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, bytes, BUF_WORD3);
-}
-
 template <int MODE>
 __global__ void __launch_bounds__(256)
     wn_block_fwd_buf(const float* __restrict__ s_in, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
@@ -389,18 +377,6 @@ __global__ void __launch_bounds__(256)
 // accesses), and the instruction count per sample drops 4x.  The weights come from LDS per MFMA group (one ds_read feeds
 // four MFMAs), the residual is fetched (an L1/L2 hit: the tap-1 lanes just read those lines) into the x registers once the
 // dilated product is done.
-typedef float f4v __attribute__((ext_vector_type(4)));
-typedef int i4v __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ f4v bload4(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
-}
-__device__ __forceinline__ void bstore4(f4v v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i4v, v), r, voff, soff, 0);
-}
-
-#ifndef W4_RELU
-#define W4_RELU relu1
-#endif
 __global__ void __launch_bounds__(256, 2)
     wn_block_fwd_w4(const float* __restrict__ s_in, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
                     const float* __restrict__ w_dense, const float* __restrict__ b_dense, float* __restrict__ s_out, int B,
@@ -450,9 +426,7 @@ __global__ void __launch_bounds__(256, 2)
     __builtin_amdgcn_sched_barrier(0);
     const float* wd_t = wdl;
     const float* we_t = wel;
-#ifndef W4_NO_LAUNDER
     asm volatile("" : "+v"(wd_t), "+v"(we_t));
-#endif
     f32x16 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
@@ -462,7 +436,7 @@ __global__ void __launch_bounds__(256, 2)
     for (int s = 0; s < 32; ++s) {
       const float w = wd_t[2 * s];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = mfma32(w, W4_RELU(x[s][j]), acc[j]);
+      for (int j = 0; j < 4; ++j) acc[j] = mfma32(w, relu1(x[s][j]), acc[j]);
     }
     // residual rows (same plane, `dil` samples later: the lines the tap-1 half just read), into registers x no longer needs
     const int offr = (t + dil) * 4 + 4 * lh * rowL;
@@ -479,7 +453,7 @@ __global__ void __launch_bounds__(256, 2)
     for (int r = 0; r < 16; ++r) {
       const float w = we_t[mfma32_row(r, 0)];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc2[j] = mfma32(w, W4_RELU(acc[j][r]), acc2[j]);
+      for (int j = 0; j < 4; ++j) acc2[j] = mfma32(w, relu1(acc[j][r]), acc2[j]);
     }
     const int offo = t * 4 + 4 * lh * rowO;
     if (t0 + 128 <= Lo) {
