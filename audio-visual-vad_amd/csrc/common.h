@@ -103,6 +103,27 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + j;
 }
 
+// XCD-aware walk of a persistent grid of 4-wave workgroups over `ntiles` wave-tiles.  Workgroups are dealt round-robin to
+// the 8 XCDs (each with its own L2), so XCD x takes the contiguous eighth [x*ntiles/8, (x+1)*ntiles/8) and its waves sweep it
+// side by side: tile j + d (the other tap, the residual, the neighbouring halo) is then a line that a wave of the SAME XCD
+// fetched a moment ago.  Dealt out by raw wave id, neighbouring tiles sat in different XCDs and every activation plane
+// crossed the fabric ~1.4-1.7 times (FETCH_SIZE: 117 -> 94 MB per encoder-layer launch for 86 MB algorithmic).  Falls back
+// to the plain strided walk when the grid is not a whole number of XCD groups.  Speed only: every tile is visited once.
+struct TileWalk { long first, last, stride; };
+__device__ __forceinline__ TileWalk xcd_walk(long ntiles) {
+  TileWalk w;
+  w.first = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  w.last = ntiles;
+  w.stride = ((long)gridDim.x * blockDim.x) >> 6;
+  if ((gridDim.x & 7) == 0 && blockDim.x == 256) {
+    const int xcd = blockIdx.x & 7;
+    w.first = ntiles * xcd / 8 + ((blockIdx.x >> 3) * 4 + (threadIdx.x >> 6));
+    w.last = ntiles * (xcd + 1) / 8;
+    w.stride = (gridDim.x >> 3) * 4;
+  }
+  return w;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -570,8 +570,9 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { svn[r] = sp[(long)mfma32_row(r, lh) * Lin]; rvn[r] = rp[(long)mfma32_row(r, lh) * Lo]; }
   };
-  if (wave0 < ntiles) issue(wave0);
-  for (long tile = wave0; tile < ntiles; tile += nwaves) {
+  const TileWalk tw = xcd_walk(ntiles);
+  if (tw.first < tw.last) issue(tw.first);
+  for (long tile = tw.first; tile < tw.last; tile += tw.stride) {
     const int b = (int)(tile / tiles_per_seq);
     const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;   // t' (input time)
     const bool ok = t < Lin;
@@ -583,7 +584,7 @@ __global__ void __launch_bounds__(256)
     for (int s = 0; s < 32; ++s) dz[s] = okz ? dzn[s] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { sv[r] = svn[r]; rv[r] = okr ? rvn[r] : 0.f; }
-    issue(tile + nwaves);
+    issue(tile + tw.stride);
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1032,8 +1033,9 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int c = 0; c < 32; ++c) xn[c] = xp[(long)c * Lin];
   };
-  if (wave0 < ntiles) issue(wave0);
-  for (long tl = wave0; tl < ntiles; tl += nwaves) {
+  const TileWalk tw = xcd_walk(ntiles);
+  if (tw.first < tw.last) issue(tw.first);
+  for (long tl = tw.first; tl < tw.last; tl += tw.stride) {
     const int b = (int)(tl / tiles_per_seq);
     const int t = (int)(tl - (long)b * tiles_per_seq) * 32 + li;
     const bool ok = t < Lo;
@@ -1044,7 +1046,7 @@ __global__ void __launch_bounds__(256)
     for (int q = 0; q < 16; ++q) g[q] = ok ? gn[q] : 0.f;
 #pragma unroll
     for (int c = 0; c < 32; ++c) x[c] = ok ? relu1(xn[c]) : 0.f;      // relu(s tap lh), zero outside the tile
-    issue(tl + nwaves);
+    issue(tl + tw.stride);
     // pin the 48 loads HERE: left alone hipcc sinks each one down to its consumer (load, wait, mfma, load, wait, ...),
     // 32 serial memory round trips per tile -- the kernel ran 2.5x slower than the two it replaces
     __builtin_amdgcn_sched_barrier(0);
