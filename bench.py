@@ -158,7 +158,7 @@ def _events(torch, fn, reps):
 
 def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
     """Per-launch duration (HIP events on the launch stream = torch's current stream) of the dominant kernel: the
-    fp32-MFMA implicit-GEMM convolution igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,...>, i.e. the forward of
+    fp32-MFMA implicit-GEMM convolution igemm::kernel<128,128,true,512,Im2colFwd<true>,ColTapRows<true>,...>, i.e. the forward of
     every trunk conv with Cout >= 128 (15 launches per step).  achieved = algorithmic FLOPs of those launches
     (2*N*Ho*Wo*Co*KS^2*C each) / their summed duration, everything the launch needs included (the GEMM kernel and,
     where a shape's tile count leaves a stream-K round, its fix-up kernel).  `traffic` is the
@@ -186,7 +186,7 @@ def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
         n_launch += 1
     ach = tot_flop / tot_ms / 1e9
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
-    return {"bound": "mfma", "kernel": "igemm::kernel<128,128,true,512,Im2colFwd,ColTapRows,EpiStore%s> (trunk conv forward, Cout>=128) + its "
+    return {"bound": "mfma", "kernel": "igemm::kernel<128,128,true,512,Im2colFwd<true>,ColTapRows<true>,EpiStore%s> (trunk conv forward, Cout>=128, buffer-addressed gathers) + its "
                                        "stream-K fix-up" % (",bf16" if dtype == "bf16" else ""),
             "launches_per_step": n_launch, "avg_launch_us": round(1e3 * tot_ms / n_launch, 2),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
@@ -197,8 +197,8 @@ def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
 
 
 def roofline_probe_hbm(torch, n_seq, L, reps=10):
-    """The dominant HBM-bound kernel: one layer-at-a-time residual block of the encoder (wn_block_fwd_mfma: R = D = 32,
-    filter width 2, the large-dilation layers that cannot be fused in LDS), timed per launch with HIP events through the
+    """The dominant HBM-bound kernel: one layer-at-a-time residual block of the encoder (wn_block_fwd_buf: R = D = 32,
+    filter width 2; planes of >= 8192 samples take the dwordx4 form wn_block_fwd_w4), timed per launch with HIP events through the
     single-layer entry point avvad_wavenet_block_fwd.  Algorithmic bytes per launch = one read of s_in + one write of
     s_out (the second tap and the residual are re-reads of the same plane: L2 hits by design) = 256 B per output sample."""
     from avvad import _lib as L_
@@ -223,7 +223,7 @@ def roofline_probe_hbm(torch, n_seq, L, reps=10):
     ms = sum(m for _, m, _ in out) / len(out)
     byts = sum(b for _, _, b in out) / len(out)
     ach = byts / ms / 1e6
-    return {"bound": "hbm", "kernel": "wn_block_fwd_mfma (encoder residual block, layer-at-a-time, R=D=32 fw=2)",
+    return {"bound": "hbm", "kernel": "wn_block_fwd_buf<0> (encoder residual block, layer-at-a-time, R=D=32 fw=2, buffer addressing, XCD-aware walk)",
             "avg_launch_us": round(1e3 * ms, 2), "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(byts), "traffic": TRAFFIC.get("wn_layer"),
             "per_dilation": [{"d": d, "us": round(1e3 * m, 1), "GBs": round(b / m / 1e6, 1)} for d, m, b in out]}
