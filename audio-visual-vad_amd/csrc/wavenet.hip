@@ -368,6 +368,75 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// HIGH-OCCUPANCY form (the default for planes shorter than 8192 samples): the same block with nothing held across tiles
+// -- weights read from LDS per MFMA instead of 48 resident registers, no cross-tile prefetch registers -- so the kernel
+// fits 4 waves per SIMD (< 128 VGPRs) and the memory latency of a tile hides under the OTHER waves' MFMAs instead of under
+// this wave's own.  Measured (tools/lab/clk_lab2.py, same body): bench-shape layer 28.4 us at 4 waves/SIMD, 28.5 at 3,
+// 31.0 at 2; C2-shape layer 273 / 303 / 380 us.  Earlier attempts at this shape (round 2, first half) ran the flat
+// addressing: with ~700 VALU instructions per tile the extra waves only queued for the vector ALUs.
+template <int MODE>
+__global__ void __launch_bounds__(256, 4)
+    wn_block_fwd_occ(const float* __restrict__ s_in, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
+                     const float* __restrict__ w_dense, const float* __restrict__ b_dense, float* __restrict__ s_out,
+                     float* __restrict__ z_out, int B, int Lin, int dil) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const int ntiles = B * tiles_per_seq;
+  __shared__ float wl[32 * 65 + 32 * 33 + 64];
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  for (int i = threadIdx.x; i < 1024; i += 256) wl[2080 + (i >> 5) * 33 + (i & 31)] = w_dense[i];
+  if (threadIdx.x < 32) {
+    wl[3136 + threadIdx.x] = b_dil ? b_dil[threadIdx.x] : 0.f;
+    wl[3168 + threadIdx.x] = b_dense ? b_dense[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  const float* wdl = wl + li * 65 + lh;              // W_dil[d = li][c = s][tap = lh] at wdl[2 s]
+  const float* wel = wl + 2080 + li * 33 + 4 * lh;   // W_dense[r = li][d = row(r', lh)] at wel[row(r', 0)]
+  const float* bzl = wl + 3136 + 4 * lh;
+  const float* bsl = wl + 3168 + 4 * lh;
+  const int rowL = Lin * 4, rowO = Lo * 4;
+  const TileWalk tw = xcd_walk(ntiles);
+  const int first = __builtin_amdgcn_readfirstlane((int)tw.first), last = (int)tw.last, stride = (int)tw.stride;
+  for (int tile = first; tile < last; tile += stride) {
+    const int b = tile / tiles_per_seq;
+    const int t = (tile - b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lo;
+    const __amdgpu_buffer_rsrc_t rx = brsrc(s_in + (long)b * 32 * Lin, 32 * rowL);
+    const int offx = ok ? (t + lh * dil) * 4 : BUF_OOB;
+    float x[32], rv[16];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = bload(rx, offx, c * rowL);
+    if (MODE <= 1) {
+      const int offr = ok ? (t + dil) * 4 + 4 * lh * rowL : BUF_OOB;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) rv[r] = bload(rx, offr, mfma32_row(r, 0) * rowL);
+    }
+    const int offo = ok ? t * 4 + 4 * lh * rowO : BUF_OOB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bzl[mfma32_row(r, 0)];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = mfma32(wdl[2 * s], relu1(x[s]), acc);
+    if (MODE >= 1) {
+      const __amdgpu_buffer_rsrc_t rz = brsrc(z_out + (long)b * 32 * Lo, 32 * rowO);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bstore(acc[r], rz, offo, mfma32_row(r, 0) * rowO);
+    }
+    if (MODE <= 1) {
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = bsl[mfma32_row(r, 0)] + rv[r];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2 = mfma32(wel[mfma32_row(r, 0)], relu1(acc[r]), acc2);
+      const __amdgpu_buffer_rsrc_t ro = brsrc(s_out + (long)b * 32 * Lo, 32 * rowO);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bstore(acc2[r], ro, offo, mfma32_row(r, 0) * rowO);
+    }
+  }
+}
+
 // WIDE form (the default for planes of >= 128 samples): the same block with 16-byte memory instructions.  The dword
 // kernels above are ISSUE-bound in the memory pipe -- 64 one-dword wave-instructions per 32-sample tile keep the CU's
 // address unit busier (~1000 cycles) than the tile's 48 MFMAs keep the matrix pipe (768), and a wave that is stuck issuing
@@ -594,6 +663,52 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       if (ok) op[(long)mfma32_row(r, lh) * Lin] = (sv[r] > 0.f ? acc[r] : 0.f) + rv[r];
+  }
+}
+
+// HIGH-OCCUPANCY form of (B), the default (see wn_block_fwd_occ): buffer addressing, weights read from LDS per MFMA,
+// nothing held across tiles -> < 128 VGPRs, 4 waves per SIMD.  Same arithmetic, same summation order.
+__global__ void __launch_bounds__(256, 4)
+    wn_block_bwd_dx_occ(const float* __restrict__ DZ, const float* __restrict__ s_in, const float* __restrict__ dS_out,
+                        const float* __restrict__ w_dil, float* __restrict__ dS_in, int B, int Lin, int dil) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lin + 31) >> 5;
+  const int ntiles = B * tiles_per_seq;
+  __shared__ float wl[32 * 65];
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  __syncthreads();
+  const float* wtl = wl + li * 2 + lh;   // A[i = c = li][k = (d = s, tap = lh)] = W_dil[d][c][tap] at wtl[65 s]
+  const int rowL = Lin * 4, rowO = Lo * 4;
+  const TileWalk tw = xcd_walk(ntiles);
+  const int first = __builtin_amdgcn_readfirstlane((int)tw.first), last = (int)tw.last, stride = (int)tw.stride;
+  for (int tile = first; tile < last; tile += stride) {
+    const int b = tile / tiles_per_seq;
+    const int t = (tile - b * tiles_per_seq) * 32 + li;   // t' (input time)
+    const bool ok = t < Lin;
+    const int to = t - lh * dil;                          // dz time of this lane half's tap
+    const bool okz = ok && to >= 0 && to < Lo;
+    const bool okr = ok && t >= dil;                      // residual: dS_out[c][t' - dil]
+    const __amdgpu_buffer_rsrc_t rz = brsrc(DZ + (long)b * 32 * Lo, 32 * rowO);
+    const __amdgpu_buffer_rsrc_t rs = brsrc(s_in + (long)b * 32 * Lin, 32 * rowL);
+    const __amdgpu_buffer_rsrc_t rg = brsrc(dS_out + (long)b * 32 * Lo, 32 * rowO);
+    const __amdgpu_buffer_rsrc_t ro = brsrc(dS_in + (long)b * 32 * Lin, 32 * rowL);
+    const int offz = okz ? to * 4 : BUF_OOB;
+    const int offs = ok ? t * 4 + 4 * lh * rowL : BUF_OOB;
+    const int offg = okr ? (t - dil) * 4 + 4 * lh * rowO : BUF_OOB;
+    float dz[32], sv[16], rv[16];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) dz[s] = bload(rz, offz, s * rowO);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { sv[r] = bload(rs, offs, mfma32_row(r, 0) * rowL); rv[r] = bload(rg, offg, mfma32_row(r, 0) * rowO); }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = mfma32(wtl[65 * s], dz[s], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bstore((sv[r] > 0.f ? acc[r] : 0.f) + rv[r], ro, offs, mfma32_row(r, 0) * rowL);
   }
 }
 
@@ -1332,8 +1447,9 @@ static void launch_block_fwd(const float* s_in, const float* wd, const float* bd
 static inline bool buf_ok(int B, int Lin) {
   return avvad_tune().wn_flat != 1 && (long)Lin * 32 * 4 + 4096 < (1L << 31) && (long)B * cdiv(Lin, 32) < (1L << 31);
 }
-// option "wn_flat": 0 by size (wide dwordx4 kernel for big planes, else the dword buffer kernel), 1 flat dword kernel,
-// 2 dword buffer kernel, 3 wide kernel
+// option "wn_flat": 0 by plane length (wide dwordx4 kernel from 8192 samples, else the high-occupancy dword kernel),
+// 1 flat dword kernel, 2 dword buffer kernel with resident weights and cross-tile prefetch, 3 wide kernel, 4 high-occupancy kernel
+constexpr int WIDE_FROM = 8192;    // plane length from which the dwordx4 kernel runs
 static void launch_block_fwd(const float* s_in, const float* wd, const float* bd, const float* we, const float* be, float* s_out,
                              int B, int Lin, int dil, hipStream_t s) {
   const int Lo = Lin - dil;
@@ -1342,7 +1458,7 @@ static void launch_block_fwd(const float* s_in, const float* wd, const float* bd
   // choice depends on the plane LENGTH only: the two forms round the residual add differently (last bit), and a sequence's
   // result must not depend on how many others share its batch.
   if (buf_ok(B, Lin) && (avvad_tune().wn_flat == 0 || avvad_tune().wn_flat == 3) && Lo >= 128 &&
-      (Lo >= 8192 || avvad_tune().wn_flat == 3)) {
+      (Lo >= WIDE_FROM || avvad_tune().wn_flat == 3)) {
     const long ntiles = (long)B * cdiv(Lo, 128);
     long blocks = (ntiles + 3) / 4;
     const long cap = avvad_tune().wn_grid > 0 ? avvad_tune().wn_grid : 1024;
@@ -1355,6 +1471,15 @@ static void launch_block_fwd(const float* s_in, const float* wd, const float* bd
   long blocks = (ntiles + 3) / 4;
   if (blocks > 512) blocks = 512;    // 2 waves per SIMD resident; each wave walks >= 5 tiles at the bench shape
   if (avvad_tune().wn_grid > 0 && blocks > avvad_tune().wn_grid) blocks = avvad_tune().wn_grid;
+  if (buf_ok(B, Lin) && (avvad_tune().wn_flat == 0 || avvad_tune().wn_flat == 4)) {
+    long ob = (ntiles + 3) / 4;                       // 4 waves per SIMD resident: 1024 workgroups
+    if (ob > 1024) ob = 1024;
+    if (avvad_tune().wn_grid > 0 && ob > avvad_tune().wn_grid) ob = avvad_tune().wn_grid;
+    if (ob >= 8) ob = ob / 8 * 8 + ((ob & 7) ? 8 : 0);
+    hipLaunchKernelGGL(wn_block_fwd_occ<0>, dim3((int)ob), dim3(256), 0, s, s_in, wd, bd, we, be, s_out, (float*)nullptr, B, Lin,
+                       dil);
+    return;
+  }
   if (buf_ok(B, Lin))
     hipLaunchKernelGGL(wn_block_fwd_buf<0>, dim3((int)blocks), dim3(256), 0, s, s_in, wd, bd, we, be, s_out, (float*)nullptr, B, Lin,
                        dil);
@@ -1558,8 +1683,14 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
         }
       }
       blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
-      if (blocks > 512) blocks = 512;
-      hipLaunchKernelGGL(wn_block_bwd_dx_mfma, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
+      if (buf_ok(B, Li) && avvad_tune().wn_flat == 0) {
+        if (blocks > 1024) blocks = 1024;                 // 4 waves per SIMD resident
+        if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
+        hipLaunchKernelGGL(wn_block_bwd_dx_occ, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
+      } else {
+        if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(wn_block_bwd_dx_mfma, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
+      }
     } else {
       // dense (1x1) layer: d W_dense = GA . relu(z)^T ; d b ; dz = (z>0) * W_dense^T GA
       if (g->dense_w_h[i] && (rc = wgrad_conv1d(GA, Zi, g->dense_w_h[i], B, R, D, Lo, Lo, 1, 1, 1, s, ws + p.gslab))) return rc;

@@ -8,7 +8,10 @@ B, L, dil = 256, 16000, 64
 blocks = int(sys.argv[1]) if len(sys.argv) > 1 else 768
 nw = blocks * 4
 x = torch.randn(B, 32, L, device="cuda"); y = torch.empty(B, 32, L - dil, device="cuda")
-for name in ("clk_full", "clk2_full", "clk_mfmaonly", "clk2_mfmaonly", "clk_memonly", "clk2_memonly"):
+names = sys.argv[2].split(",") if len(sys.argv) > 2 else ("clk_full", "clk2_full", "clk_mfmaonly", "clk2_mfmaonly", "clk_memonly", "clk2_memonly")
+if len(sys.argv) > 5: B, L, dil = int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+x = torch.randn(B, 32, L, device="cuda"); y = torch.empty(B, 32, L - dil, device="cuda")
+for name in names:
     fn = getattr(lib, "launch_" + name)
     fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
     stamp = torch.zeros(4 * nw, dtype=torch.int64, device="cuda")
