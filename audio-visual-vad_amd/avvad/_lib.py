@@ -34,7 +34,7 @@ class GemmDesc(C.Structure):
 class WavenetDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("L", C.c_int), ("qc", C.c_int), ("R", C.c_int), ("D", C.c_int), ("Bn", C.c_int),
                 ("fw", C.c_int), ("P", C.c_int), ("n_layers", C.c_int), ("dilations_h", C.POINTER(C.c_int)),
-                ("use_bias", C.c_int), ("save_for_backward", C.c_int)]
+                ("use_bias", C.c_int), ("save_for_backward", C.c_int), ("shared_device", C.c_int)]
 
 
 class WavenetPtrs(C.Structure):  # avvad_wavenet_params and avvad_wavenet_grads share this layout

@@ -205,9 +205,12 @@ class WavenetFn(torch.autograd.Function):
 
     @staticmethod
     def _desc(cfg, B, Lin, dil_arr, save):
+        # shared_device: this call runs on the side stream next to the trunk's kernels (DeepVAD_AV with overlap)
+        dev = torch.cuda.current_device()
+        shared = _OVERLAP and dev in _SIDE and torch.cuda.current_stream() == _SIDE[dev]
         return L.WavenetDesc(B, Lin, cfg["quantization_channel"], cfg["en_residual_channel"], cfg["en_dilation_channel"],
                              cfg["en_bottleneck_width"], cfg["filter_width"], cfg["en_pool_kernel_size"],
-                             len(cfg["dilations"]), dil_arr, int(cfg["use_bias"]), int(save))
+                             len(cfg["dilations"]), dil_arr, int(cfg["use_bias"]), int(save), int(shared))
 
     @staticmethod
     def _ptrs(ts, n):

@@ -24,13 +24,14 @@ const OptName kOpts[] = {
     {"no_buf", "AVVAD_NO_BUF", &AvvadTune::no_buf},
     {"wn_flat", "AVVAD_WN_FLAT", &AvvadTune::wn_flat},
     {"wn_grid", "AVVAD_WN_GRID", &AvvadTune::wn_grid},
+    {"wn_dx", "AVVAD_WN_DX", &AvvadTune::wn_dx},
     {"bf16", "AVVAD_BF16", &AvvadTune::bf16},
     {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
 };
 int parse_opt(const char* name, const char* v) {
   if (!strcmp(name, "igemm_variant")) return v[0] == 'd' ? 0 : (v[0] == 's' ? 1 : (v[0] == 'w' ? 2 : atoi(v)));
   if (!strcmp(name, "no_streamk")) return v[0] == 'a' ? 1 : (v[0] >= '0' && v[0] <= '9' && !v[1] ? 10 + (v[0] - '0') : atoi(v));
-  if (!strcmp(name, "max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid")) return atoi(v);
+  if (!strcmp(name, "max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid") || !strcmp(name, "wn_dx")) return atoi(v);
   return (v[0] && strcmp(v, "0")) ? 1 : 0;
 }
 }  // namespace

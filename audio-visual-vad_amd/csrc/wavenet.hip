@@ -1683,7 +1683,11 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
         }
       }
       blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
-      if (buf_ok(B, Li) && avvad_tune().wn_flat == 0) {
+      // Beside the trunk's backward on another stream (shared_device) the high-occupancy dx kernel costs the STEP 0.16 ms
+      // although it is 15 % faster alone: 1024 workgroups of it displace the convolutions' persistent workers more
+      // often.  Option wn_dx: 1 forces the resident-weights kernel, 2 the high-occupancy one.
+      const bool dx_occ = avvad_tune().wn_dx == 2 || (avvad_tune().wn_dx == 0 && !d->shared_device);
+      if (buf_ok(B, Li) && avvad_tune().wn_flat != 1 && dx_occ) {
         if (blocks > 1024) blocks = 1024;                 // 4 waves per SIMD resident
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
         hipLaunchKernelGGL(wn_block_bwd_dx_occ, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);

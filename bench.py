@@ -283,6 +283,8 @@ def main():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: BASELINE configs[4] arithmetic (own line, never the headline)")
     ap.add_argument("--reserve-cus", type=int, default=0, help="CUs left free by the persistent conv grids (room for RCCL kernels at N>1)")
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / parity probes")
+    ap.add_argument("--ab", default="", help="tuning aid: after the timed region, time the step under library option NAME=VALUE\n"
+                    "against its current value, A/B/A/B in this process (stderr; boxes differ by several %)")
     args = ap.parse_args()
 
     import torch
@@ -371,6 +373,22 @@ def main():
         dt = float(tt.item())
     final_loss = float(loss.item())
     log("timed region: %.3f s for %d steps" % (dt, args.steps))
+    if args.ab and world == 1:
+        from avvad import _lib as L_
+        name, val = args.ab.split("=")
+        base = L_.get_option(name)
+        for rep in range(3):
+            for v_ in (base, int(val)):
+                L_.set_option(name, v_)
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                ta = time.perf_counter()
+                for _ in range(args.steps):
+                    step()
+                torch.cuda.synchronize()
+                log("A/B %s=%d: %.3f ms/step" % (name, v_, 1e3 * (time.perf_counter() - ta) / args.steps))
+        L_.set_option(name, base)
 
     if rank == 0:
         fp_per_step = world * n_seq * T

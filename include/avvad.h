@@ -43,7 +43,7 @@ int avvad_abi_version(void);
 
 /* Schedule options (tuning / debugging; production leaves them alone).  Names: "no_streamk" (1 = whole-tile,
  * bit-reproducible GEMM schedule), "igemm_variant", "kmajor", "lstm_no_fused_step", "lstm_no_persistent",
- * "no_stem_kernel", "no_tall", "wn_no_fused_tail", "wn_no_fused_wgrad", "wn_bwd_t", "wn_flat", "wn_grid", "no_buf", "bf16" (bf16-input MFMA with fp32
+ * "no_stem_kernel", "no_tall", "wn_no_fused_tail", "wn_no_fused_wgrad", "wn_bwd_t", "wn_flat", "wn_grid", "wn_dx", "no_buf", "bf16" (bf16-input MFMA with fp32
  * accumulation for the trunk convolutions and the dense GEMMs -- BASELINE config 5's mixed precision; storage, BatchNorm
  * statistics, LSTM cell, loss and Adam stay fp32; never the default), "max_cus" (cap on the CUs
  * a persistent grid occupies, so that RCCL's kernels find free CUs during data-parallel training).  Initial values
@@ -97,6 +97,8 @@ typedef struct {
   const int* dilations_h; /* host array [n_layers]                     */
   int use_bias;
   int save_for_backward; /* forward keeps every s_i in the workspace (z_i is rebuilt by the backward) */
+  int shared_device;     /* hint: another stream's kernels run beside this call (the AV model's trunk on the main stream):
+                            prefer the kernel forms that interfere least with them.  0 = the device is ours        */
 } avvad_wavenet_desc;
 
 /* parameter pointers, host arrays of device pointers */
