@@ -197,7 +197,7 @@ def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
 
 
 def roofline_probe_hbm(torch, n_seq, L, reps=10):
-    """The dominant HBM-bound kernel: one layer-at-a-time residual block of the encoder (wn_block_fwd_buf: R = D = 32,
+    """The dominant HBM-bound kernel: one layer-at-a-time residual block of the encoder (wn_block_fwd_occ: R = D = 32,
     filter width 2; planes of >= 8192 samples take the dwordx4 form wn_block_fwd_w4), timed per launch with HIP events through the
     single-layer entry point avvad_wavenet_block_fwd.  Algorithmic bytes per launch = one read of s_in + one write of
     s_out (the second tap and the residual are re-reads of the same plane: L2 hits by design) = 256 B per output sample."""
@@ -223,7 +223,7 @@ def roofline_probe_hbm(torch, n_seq, L, reps=10):
     ms = sum(m for _, m, _ in out) / len(out)
     byts = sum(b for _, _, b in out) / len(out)
     ach = byts / ms / 1e6
-    return {"bound": "hbm", "kernel": "wn_block_fwd_buf<0> (encoder residual block, layer-at-a-time, R=D=32 fw=2, buffer addressing, XCD-aware walk)",
+    return {"bound": "hbm", "kernel": "wn_block_fwd_occ<0> (encoder residual block, layer-at-a-time, R=D=32 fw=2, buffer addressing, 4 waves/SIMD, XCD-aware walk)",
             "avg_launch_us": round(1e3 * ms, 2), "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_launch": int(byts), "traffic": TRAFFIC.get("wn_layer"),
             "per_dilation": [{"d": d, "us": round(1e3 * m, 1), "GBs": round(b / m / 1e6, 1)} for d, m, b in out]}

@@ -25,7 +25,7 @@ def traffic(k):
 
 
 conv = find("kernel<128, 128, true, 512", "Im2colFwd", "false>")
-wn = find("wn_block_fwd_buf<0>")
+wn = find("wn_block_fwd_occ<0>")
 print(json.dumps({
     "conv_fwd": traffic(conv), "conv_fwd_kernel": conv,
     "wn_layer": traffic(wn), "wn_layer_kernel": wn,
