@@ -44,7 +44,7 @@ struct Plan {
   size_t part;                                    // doubles: [STAT_CHUNKS][2][MAXC]
   size_t c0, p0, am;   // am: arg-max position (0..8, one byte per channel) of every pooled stem element
   size_t blk[8][5];  // c1, a1, c2, cd, out
-  size_t G[4], g0, wg;
+  size_t G[4], g0, wg[NCONV];   // wg[i]: conv i's packed weight gradient (all 20 kept: ONE unpack launch at the end)
   size_t slab;     // igemm::SLAB_FLOATS: partial tiles of the engine's stream-K round
   size_t total;
 };
@@ -106,7 +106,7 @@ static void make_plan(const avvad_trunk_desc* d, Plan* p) {
     const size_t gmax = N * p->h[2] * p->w[2] * 64;  // stage0 is the largest block tensor
     for (int j = 0; j < 4; ++j) p->G[j] = take(gmax);
     p->g0 = take(N * p->h[1] * p->w[1] * 64);
-    p->wg = take((size_t)9 * 512 * 512);
+    for (int j = 0; j < NCONV; ++j) p->wg[j] = take((size_t)p->conv[j].ks * p->conv[j].ks * p->conv[j].cin * p->conv[j].cout);
   }
   p->total = off;
 }
@@ -164,21 +164,34 @@ __global__ void pack_stem(const float* __restrict__ w, float* __restrict__ wf) {
   const int co = i / 49, k = i % 49;
   wf[k * 64 + co] = w[(co * 3 + 0) * 49 + k] + w[(co * 3 + 1) * 49 + k] + w[(co * 3 + 2) * 49 + k];
 }
-__global__ void unpack_wgrad(const float* __restrict__ pk, float* __restrict__ dw, int Co, int C, int KS) {
-  const int n = Co * C * KS * KS;
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    int r = i;
-    const int kw = r % KS; r /= KS;
-    const int kh = r % KS; r /= KS;
-    const int c = r % C; const int co = r / C;
-    dw[i] += pk[((long)(kh * KS + kw) * C + c) * Co + co];
+// every convolution's packed gradient -> += the OIHW gradient, ONE launch behind the last weight-gradient GEMM (19 launches
+// of ~8 us each were 0.15 ms of the step; the whole trunk is one autograd node, nobody consumes a gradient earlier)
+struct UnpackTab {
+  const float* pk[NCONV];
+  float* dw[NCONV];        // null: this convolution's gradient is not wanted
+  int cout[NCONV], cin[NCONV], ks[NCONV];
+  int blk0[NCONV + 1];
+};
+__global__ void __launch_bounds__(256) unpack_all(const UnpackTab tab) {
+  int i = 0;
+#pragma unroll
+  for (int j = 1; j < NCONV; ++j) i += (int)blockIdx.x >= tab.blk0[j];      // block-uniform
+  const int e = ((int)blockIdx.x - tab.blk0[i]) * 256 + threadIdx.x;
+  float* dw = tab.dw[i];
+  if (!dw) return;
+  const float* pk = tab.pk[i];
+  if (i == 0) {
+    if (e >= 64 * 3 * 49) return;
+    dw[e] += pk[(e % 49) * 64 + e / 147];
+    return;
   }
-}
-__global__ void unpack_stem_wgrad(const float* __restrict__ pk, float* __restrict__ dw) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 64 * 3 * 49) return;
-  const int co = i / 147, k = i % 49;
-  dw[i] += pk[k * 64 + co];
+  const int Co = tab.cout[i], C = tab.cin[i], KS = tab.ks[i];
+  if (e >= Co * C * KS * KS) return;
+  int r = e;
+  const int kw = r % KS; r /= KS;
+  const int kh = r % KS; r /= KS;
+  const int c = r % C; const int co = r / C;
+  dw[e] += pk[((long)(kh * KS + kw) * C + c) * Co + co];
 }
 
 // ------------------------------------------------------------------ stem convolution 7x7 / 2, 1 -> 64 channels (frames that fit LDS)
@@ -669,19 +682,12 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
   float* G1 = ws + p.G[1];
   float* G2 = ws + p.G[2];
   float* G3 = ws + p.G[3];
-  float* wg = ws + p.wg;
   // d(out of last block) from the average pool
   hipLaunchKernelGGL(avgpool_bwd, dim3(ew_grid(N * p.h[5] * p.w[5] * 512)), dim3(256), 0, s, dfeat, G0, d->N,
                      p.h[5] * p.w[5], 512);
   auto wgrad = [&](int i, const float* xin, const float* dyraw) -> int {
     if (!g->conv_w[i]) return AVVAD_OK;
-    int r = conv_wgrad(xin, dyraw, wg, p.geom[i], s, ws + p.slab);
-    if (r) return r;
-    const ConvSpec& c = p.conv[i];
-    if (i == 0) hipLaunchKernelGGL(unpack_stem_wgrad, dim3(cdiv(64 * 147, 256)), dim3(256), 0, s, wg, g->conv_w[0]);
-    else hipLaunchKernelGGL(unpack_wgrad, dim3(ew_grid(c.cout * c.cin * c.ks * c.ks)), dim3(256), 0, s, wg, g->conv_w[i],
-                            c.cout, c.cin, c.ks);
-    return AVVAD_OK;
+    return conv_wgrad(xin, dyraw, ws + p.wg[i], p.geom[i], s, ws + p.slab);   // unpacked at the end (unpack_all)
   };
   int ci = NCONV;
   for (int st = 3; st >= 0; --st)
@@ -721,6 +727,23 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
     // in place: d c0 overwrites g0
     if ((rc = bn_backward(&p, ws, 0, ws + p.c0, g0, nullptr, g0, nullptr, M0, prm, g, d, s))) return rc;
     if ((rc = wgrad(0, frames, g0))) return rc;
+  }
+  {
+    UnpackTab tab;
+    int nb = 0;
+    bool any = false;
+    for (int i = 0; i < NCONV; ++i) {
+      const ConvSpec& c = p.conv[i];
+      const bool done = g->conv_w[i] && (i > 0 || g->conv_w[0]);
+      tab.pk[i] = ws + p.wg[i];
+      tab.dw[i] = done ? g->conv_w[i] : (float*)nullptr;
+      tab.cout[i] = c.cout; tab.cin[i] = c.cin; tab.ks[i] = c.ks;
+      tab.blk0[i] = nb;
+      nb += cdiv(i == 0 ? 64 * 3 * 49 : (long)c.cout * c.cin * c.ks * c.ks, 256);
+      any = any || done;
+    }
+    tab.blk0[NCONV] = nb;
+    if (any) hipLaunchKernelGGL(unpack_all, dim3(nb), dim3(256), 0, s, tab);
   }
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
