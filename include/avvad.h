@@ -41,13 +41,18 @@ typedef void* avvad_stream_t; /* hipStream_t */
 const char* avvad_version(void);
 int avvad_abi_version(void);
 
-/* Schedule options (tuning / debugging; production leaves them alone).  Names: "no_streamk" (1 = whole-tile,
- * bit-reproducible GEMM schedule), "igemm_variant", "kmajor", "lstm_no_fused_step", "lstm_no_persistent",
- * "no_stem_kernel", "no_tall", "wn_no_fused_tail", "wn_no_fused_wgrad", "wn_bwd_t", "wn_flat", "wn_grid", "wn_dx", "no_buf", "bf16" (bf16-input MFMA with fp32
- * accumulation for the trunk convolutions and the dense GEMMs -- BASELINE config 5's mixed precision; storage, BatchNorm
- * statistics, LSTM cell, loss and Adam stay fp32; never the default), "max_cus" (cap on the CUs
- * a persistent grid occupies, so that RCCL's kernels find free CUs during data-parallel training).  Initial values
- * come from AVVAD_<NAME> in the environment, read once.  Returns AVVAD_EINVAL for an unknown name. */
+/* Schedule options (tuning / debugging; production leaves them alone).  Names:
+ *   "no_streamk" (1 = whole-tile GEMM schedule), "igemm_variant", "kmajor", "no_tall", "no_stem_kernel",
+ *   "no_buf" (1 = convolution gathers with flat addressing + validity selects, the form operands >= 2 GiB use),
+ *   "lstm_no_fused_step", "lstm_no_persistent", "wn_no_fused_tail", "wn_no_fused_wgrad", "wn_bwd_t",
+ *   "wn_flat" (encoder block forward: 0 by plane length, 1 flat dword kernel, 2 buffer dword kernel with resident
+ *   weights, 3 dwordx4 kernel, 4 high-occupancy kernel), "wn_dx" (0 by the descriptor's shared_device hint, 1 / 2 force
+ *   a form), "wn_grid" (workgroup cap of the encoder block kernels),
+ *   "bf16" (bf16-input MFMA with fp32 accumulation for the trunk convolutions and the dense GEMMs -- BASELINE config 5's
+ *   mixed precision; storage, BatchNorm statistics, LSTM cell, loss and Adam stay fp32; never the default),
+ *   "max_cus" (cap on the CUs a persistent grid occupies, so that RCCL's kernels find free CUs during data-parallel
+ *   training).
+ * Initial values come from AVVAD_<NAME> in the environment, read once.  Returns AVVAD_EINVAL for an unknown name. */
 int avvad_set_option(const char* name, int value);
 int avvad_get_option(const char* name);
 

@@ -126,6 +126,20 @@ def test_schedule_options_are_a_table_not_the_environment(monkeypatch):
     L.set_option("no_streamk", base)
     with pytest.raises(L.AvvadError):
         L.set_option("no_such_option", 1)
+    # every option include/avvad.h names is known to the library, and the integer-valued ones keep their value
+    import re
+    hdr = open(os.path.join(ROOT, "include", "avvad.h")).read()
+    doc = hdr[hdr.index("/* Schedule options"):hdr.index("int avvad_set_option")]
+    names = set(re.findall(r'"([a-z0-9_]+)"', doc))
+    assert {"no_streamk", "bf16", "max_cus", "wn_flat", "wn_grid", "wn_dx", "no_buf", "wn_bwd_t"} <= names, names
+    for n in names:
+        v = L.get_option(n)
+        L.set_option(n, v)
+    for n, v in (("wn_flat", 3), ("wn_grid", 520), ("wn_dx", 2), ("max_cus", 200)):
+        old = L.get_option(n)
+        L.set_option(n, v)
+        assert L.get_option(n) == v
+        L.set_option(n, old)
 
 
 def test_standardisation_stats_and_waveform_loader(tmp_path):
