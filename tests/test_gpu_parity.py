@@ -168,12 +168,20 @@ def test_engine_cu_cap_option(lib_options):
 
 # ------------------------------------------------------------------------------------------ WaveNet encoder
 @pytest.mark.parametrize("name,alt", [("wn_tiny", 0), ("wn_fw3_qc2", 0), ("wn_nobias", 0), ("wn_w0", 0), ("wn_w0_t16", 0),
-                                      ("wn_nobias", 1), ("wn_w0", 1), ("wn_w0_t16", 1)])
+                                      ("wn_nobias", 1), ("wn_w0", 1), ("wn_w0_t16", 1), ("wn_w0", 2), ("wn_w0_t16", 2),
+                                      ("wn_nobias", 3), ("wn_w0", 3)])
 def test_wavenet_golden(name, alt, lib_options):
-    """alt=1: the alternate block backward kept in the library (transposed products, no LDS transposes)."""
+    """alt=1: the alternate block backward kept in the library (transposed products, no LDS transposes); alt=2: the kernel
+    forms picked beside another stream (dx with resident weights, forward with resident weights + cross-tile prefetch);
+    alt=3: round 1's flat-addressed kernels."""
     from packages.models.wavenet_autoencoder import wavenet_autoencoder
-    if alt:
+    if alt == 1:
         lib_options("wn_bwd_t", 1)
+    elif alt == 2:
+        lib_options("wn_dx", 1)
+        lib_options("wn_flat", 2)
+    elif alt == 3:
+        lib_options("wn_flat", 1)
     g = load_golden(name)
     cfg = wn_cfg_from(g)
     m = wavenet_autoencoder(**cfg)
@@ -907,7 +915,7 @@ def test_input_standardisation_in_the_train_loop():
                                              (256, 16000, 512, 0), (256, 15999, 1, 0), (64, 14977, 256, 0)])
 def test_wavenet_block_kernel_forms_agree(B, Lin, dil, grid, lib_options):
     """One residual block through avvad_wavenet_block_fwd in its three forms (option wn_flat: 1 flat dword addressing,
-    2 buffer dword, 3 wide dwordx4) against the plain torch fp32 statement of the block (wavenet_autoencoder.py:78-86);
+    2 buffer dword, 3 wide dwordx4, 4 high occupancy) against the plain torch fp32 statement of the block (wavenet_autoencoder.py:78-86);
     a small workgroup cap (wn_grid) makes every wave walk several tiles, tails included."""
     import ctypes as C
     import torch.nn.functional as F
@@ -923,7 +931,7 @@ def test_wavenet_block_kernel_forms_agree(B, Lin, dil, grid, lib_options):
         ref = (ref + s_in.double()[:, :, dil:]).float()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     outs = {}
-    for form in (1, 2, 3):
+    for form in (1, 2, 3, 4):
         lib_options("wn_flat", form)
         lib_options("wn_grid", grid)
         out = torch.full((B, 32, Lin - dil), float("nan"), device=DEV)
@@ -935,7 +943,7 @@ def test_wavenet_block_kernel_forms_agree(B, Lin, dil, grid, lib_options):
             ref = out
         assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), "form %d" % form
         outs[form] = out
-    assert torch.equal(outs[1], outs[2])          # same arithmetic, different addressing
+    assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[4])     # same arithmetic, different addressing
 
 
 def _max_rel(a, b):
