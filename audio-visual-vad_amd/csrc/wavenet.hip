@@ -1102,9 +1102,7 @@ __global__ void __launch_bounds__(256)
   const int li = lane & 31, lh = lane >> 5;
   const int Lo = Lin - dil;
   const int tiles_per_seq = (Lo + 31) >> 5;
-  const long ntiles = (long)B * tiles_per_seq;
-  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-  const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int ntiles = B * tiles_per_seq;
   float* T = tile[wave][0];
   float* Th = tile[wave][lh];           // this lane half's tile for the two-tap transpose
   for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
@@ -1125,50 +1123,48 @@ __global__ void __launch_bounds__(256)
   float wd[32];   // W_dil[d = li][c = s][tap = lh]  (the forward's fragment)
 #pragma unroll
   for (int s = 0; s < 32; ++s) wd[s] = wl[li * 65 + s * 2 + lh];
-  const float* bzl = wl + 2080;
+  const float* bzl = wl + 2080 + 4 * lh;
   __builtin_amdgcn_wave_barrier();
 
   f32x16 acc0, acc1, acc2;
 #pragma unroll
   for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
   float bs_dz = 0.f, bs_ds = 0.f;
+  const int rowL = Lin * 4, rowO = Lo * 4;
 
-  // software pipeline across tiles (as in wn_block_fwd_mfma): the NEXT tile's 48 loads are issued before this tile's 96
-  // MFMAs and LDS transposes -- with one wave per SIMD nothing else hides their latency
-  float gn[16], xn[32];
-  auto issue = [&](long tile) {
-    const long tc = tile < ntiles ? tile : ntiles - 1;
-    const int b = (int)(tc / tiles_per_seq);
-    const int t = (int)(tc - (long)b * tiles_per_seq) * 32 + li;
-    const int tcl = t < Lo ? t : 0;
-    const long oo = (long)b * 32 * Lo + tcl;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) gn[q] = dS[oo + (long)(2 * q + lh) * Lo];
-    const float* xp = s_in + (long)b * 32 * Lin + tcl + lh * dil;
-#pragma unroll
-    for (int c = 0; c < 32; ++c) xn[c] = xp[(long)c * Lin];
-  };
-  const TileWalk tw = xcd_walk(ntiles);
-  if (tw.first < tw.last) issue(tw.first);
-  for (long tl = tw.first; tl < tw.last; tl += tw.stride) {
-    const int b = (int)(tl / tiles_per_seq);
-    const int t = (int)(tl - (long)b * tiles_per_seq) * 32 + li;
+  // One wave per SIMD is resident (368 registers), so VALU instructions add to the 96 MFMAs of a tile one for one (~4
+  // cycles each): the flat-addressed version of this kernel carried 1225 of them per tile -- 64-bit address arithmetic
+  // for 64 memory instructions, a validity select on every loaded value, two-instruction ReLUs.  Buffer addressing
+  // (common.h): samples past the end of a sequence carry an out-of-range offset, their loads return 0 and their stores are
+  // dropped; a zero dS column makes every product of that column zero, so nothing downstream needs masking.
+  // Software pipeline across tiles: the NEXT tile's 48 loads are issued before this tile's 96 MFMAs and LDS transposes
+  // (nothing else hides their latency), alternating between two register sets instead of copying.
+  auto issue = [&](int tile, float (&gn)[16], float (&xn)[32]) {
+    const int tc = tile < ntiles ? tile : ntiles - 1;
+    const int b = tc / tiles_per_seq;
+    const int t = (tc - b * tiles_per_seq) * 32 + li;
     const bool ok = t < Lo;
-    const int tcl = ok ? t : 0;
-    const long oo = (long)b * 32 * Lo + tcl;
-    float g[16], x[32];     // unconditional, clamped loads (masked here)
+    const __amdgpu_buffer_rsrc_t rg = brsrc(dS + (long)b * 32 * Lo, 32 * rowO);
+    const __amdgpu_buffer_rsrc_t rx = brsrc(s_in + (long)b * 32 * Lin, 32 * rowL);
+    const int offg = ok ? t * 4 + lh * rowO : BUF_OOB;
+    const int offx = ok ? (t + lh * dil) * 4 : BUF_OOB;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) g[q] = ok ? gn[q] : 0.f;
+    for (int q = 0; q < 16; ++q) gn[q] = bload(rg, offg, 2 * q * rowO);
 #pragma unroll
-    for (int c = 0; c < 32; ++c) x[c] = ok ? relu1(xn[c]) : 0.f;      // relu(s tap lh), zero outside the tile
-    issue(tl + tw.stride);
-    // pin the 48 loads HERE: left alone hipcc sinks each one down to its consumer (load, wait, mfma, load, wait, ...),
-    // 32 serial memory round trips per tile -- the kernel ran 2.5x slower than the two it replaces
-    __builtin_amdgcn_sched_barrier(0);
-    // z exactly as wn_block_fwd_mfma builds it
+    for (int c = 0; c < 32; ++c) xn[c] = bload(rx, offx, c * rowL);
+  };
+  auto compute = [&](int tidx, const float (&g)[16], const float (&xraw)[32]) {
+    const int b = tidx / tiles_per_seq;
+    const int t = (tidx - b * tiles_per_seq) * 32 + li;
+    const int offo = t < Lo ? t * 4 + 4 * lh * rowO : BUF_OOB;
+    const __amdgpu_buffer_rsrc_t rz = brsrc(DZ + (long)b * 32 * Lo, 32 * rowO);
+    float x[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = relu1(xraw[c]);      // relu(s tap lh); 0 outside the sequence
+    // z exactly as the forward builds it
     f32x16 z;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) z[r] = bzl[mfma32_row(r, lh)];
+    for (int r = 0; r < 16; ++r) z[r] = bzl[mfma32_row(r, 0)];
 #pragma unroll
     for (int s = 0; s < 32; ++s) z = mfma32(wd[s], x[s], z);
     f32x16 acc;
@@ -1181,8 +1177,8 @@ __global__ void __launch_bounds__(256)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float dz = (ok && z[r] > 0.f) ? acc[r] : 0.f;
-      if (ok) DZ[oo + (long)mfma32_row(r, lh) * Lo] = dz;
+      const float dz = z[r] > 0.f ? acc[r] : 0.f;            // (a column past the sequence has dS = 0, so acc = 0)
+      bstore(dz, rz, offo, mfma32_row(r, 0) * rowO);
       T[mfma32_row(r, lh) * 33 + li] = dz;
     }
     __builtin_amdgcn_wave_barrier();
@@ -1202,11 +1198,11 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc1 = mfma32(f0[q], f1[q], acc1);
     __builtin_amdgcn_wave_barrier();
-    // ---- dS (channel 2q+lh on register q) and relu(z) (D layout)
+    // ---- dS (channel 2q+lh on register q) and relu(z) (D layout; multiplied by dS = 0 past the sequence)
 #pragma unroll
     for (int q = 0; q < 16; ++q) T[(2 * q + lh) * 33 + li] = g[q];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile[wave][1][mfma32_row(r, lh) * 33 + li] = ok ? relu1(z[r]) : 0.f;
+    for (int r = 0; r < 16; ++r) tile[wave][1][mfma32_row(r, lh) * 33 + li] = relu1(z[r]);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int q = 0; q < 16; ++q) { f0[q] = T[li * 33 + 2 * q + lh]; bs_ds += f0[q]; }
@@ -1215,17 +1211,41 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc2 = mfma32(f0[q], f1[q], acc2);
     __builtin_amdgcn_wave_barrier();
+  };
+  const TileWalk tw = xcd_walk(ntiles);
+  const int first = __builtin_amdgcn_readfirstlane((int)tw.first), last = (int)tw.last, stride = (int)tw.stride;
+  float ga[16], xa[32], gb[16], xb[32];
+  if (first < last) issue(first, ga, xa);
+  for (int tl = first; tl < last; tl += 2 * stride) {
+    issue(tl + stride, gb, xb);
+    // pin the 48 loads HERE: left alone hipcc sinks each one down to its consumer (load, wait, mfma, load, wait, ...),
+    // 32 serial memory round trips per tile -- the kernel ran 2.5x slower than the two it replaces
+    __builtin_amdgcn_sched_barrier(0);
+    compute(tl, ga, xa);
+    if (tl + stride >= last) break;
+    issue(tl + 2 * stride, ga, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(tl + stride, gb, xb);
   }
 
+  // the four waves' sums meet in LDS in WAVE ORDER (plain adds between barriers: float atomics here added them in
+  // arrival order, the one place left where this kernel's result could differ in the last bit from run to run)
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int row = mfma32_row(r, lh);
-    atomicAdd(&red[row * 32 + li], acc0[r]);
-    atomicAdd(&red[1024 + row * 32 + li], acc1[r]);
-    atomicAdd(&red[2048 + row * 32 + li], acc2[r]);
+      for (int r = 0; r < 16; ++r) {
+        const int row = mfma32_row(r, lh);
+        red[row * 32 + li] += acc0[r];
+        red[1024 + row * 32 + li] += acc1[r];
+        red[2048 + row * 32 + li] += acc2[r];
+      }
+      // the bias sums: both lane halves hold partial sums of the same 32 channels -> half 0 first, then half 1
+      if (lh == 0) { red[3072 + li] += bs_dz; red[3104 + li] += bs_ds; }
+      __builtin_amdgcn_wave_barrier();
+      if (lh == 1) { red[3072 + li] += bs_dz; red[3104 + li] += bs_ds; }
+    }
   }
-  atomicAdd(&red[3072 + li], bs_dz);
-  atomicAdd(&red[3104 + li], bs_ds);
   __syncthreads();
   float* out = slab + (long)blockIdx.x * WG_SLAB;
   for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
