@@ -886,17 +886,22 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 16; ++r) accW[n][r] = 0.f;
   }
+  // buffer addressing (common.h): one wave per SIMD is resident, so every VALU instruction adds to the MFMA time; the flat
+  // form spent ~1150 of them per tile on the 64-bit addresses of the 384 pooled-gradient gathers alone
+  const int rowV = Lv * 4;
   for (long tile = wave0; tile < ntiles; tile += nwaves) {
-    const int b = (int)(tile / tiles_per_seq);
+    const int b = __builtin_amdgcn_readfirstlane((int)(tile / tiles_per_seq));
     const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
     const bool ok = t < Lv;
-    const float* sp = s + (long)b * 32 * Lv + (ok ? t : 0);
+    const __amdgpu_buffer_rsrc_t rs = brsrc(s + (long)b * 32 * Lv, 32 * rowV);
+    const __amdgpu_buffer_rsrc_t rd = brsrc(dS + (long)b * 32 * Lv, 32 * rowV);
+    const __amdgpu_buffer_rsrc_t rg = brsrc(dout + (long)b * Bn * P, Bn * P * 4);
+    const int offs = ok ? t * 4 + lh * rowV : BUF_OOB;            // s row 2k + lh
+    const int offd = ok ? t * 4 + 4 * lh * rowV : BUF_OOB;        // dS row mfma32_row(r, lh)
     float x[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = sp[(long)(2 * k + lh) * Lv];
+    for (int k = 0; k < 16; ++k) x[k] = bload(rs, offs, 2 * k * rowV);   // 0 past the sequence
     __builtin_amdgcn_sched_barrier(0);     // keep the 16 loads together (see wn_block_bwd_dz_wgrad_mfma)
-#pragma unroll
-    for (int k = 0; k < 16; ++k) x[k] = ok ? x[k] : 0.f;
     int pb[3];
     float pc[3];
     {
@@ -912,6 +917,9 @@ __global__ void __launch_bounds__(256)
         pc[j] = hit ? 1.f / (float)(e - a) : 0.f;
       }
     }
+    int pbo[3];       // byte offset of (row 4 lh, bin pb[j]) inside this sequence's dout slab; the row of register r is scalar
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pbo[j] = (pb[j] + 4 * lh * P) * 4;
     // s tile -> fragment fs[q] = s[c = li][t = 2q + lh]  (B operand of the weight-gradient products)
     float fs[16];
     __builtin_amdgcn_wave_barrier();
@@ -940,10 +948,9 @@ __global__ void __launch_bounds__(256)
       float dz[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const long o = ((long)b * Bn + nb + mfma32_row(r, lh)) * P;
         float g = 0.f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) g = fmaf(dout[o + pb[j]], pc[j], g);   // pb clamped to a valid bin, pc = 0 when not a member
+        for (int j = 0; j < 3; ++j) g = fmaf(bload(rg, pbo[j], (nb + mfma32_row(r, 0)) * P * 4), pc[j], g);   // pb clamped to a valid bin, pc = 0 when not a member
         dz[r] = accZ[r] > 0.f ? g : 0.f;                                   // (0 outside the sequence: pc = 0)
       }
 #pragma unroll
@@ -960,8 +967,7 @@ __global__ void __launch_bounds__(256)
       for (int q = 0; q < 16; ++q) accW[n] = mfma32(fz[q], fs[q], accW[n]);
     }
 #pragma unroll
-    for (int r = 0; r < 16; ++r)
-      if (ok) dS[((long)b * 32 + mfma32_row(r, lh)) * Lv + t] = accS[r];
+    for (int r = 0; r < 16; ++r) bstore(accS[r], rd, offd, mfma32_row(r, 0) * rowV);
   }
 #pragma unroll
   for (int n = 0; n < NBT; ++n) {
