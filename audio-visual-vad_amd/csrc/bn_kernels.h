@@ -12,20 +12,28 @@ constexpr int STAT_CHUNKS = 1024;   // workgroups of a column reduction (4 per C
 // ------------------------------------------------------------------ column reductions ([M][C] fp32 -> per-channel fp64 sums)
 // MODE 0: sum x, sum x^2           (batch statistics)
 // MODE 1: sum g, sum g*xhat  with g = dy * (ymask > 0 if ymask)   (BatchNorm backward)
+//         msc/msh (instead of ymask): the ReLU mask of a BatchNorm whose output went straight into a ReLU is rebuilt from x
+//         itself, fmaf(x, msc[c], msh[c]) > 0 -- the forward's own expression on the saved scale/shift, so the same bits --
+//         and the activation tensor is not read at all (one of the three planes this pass streams)
 template <int MODE>
 __global__ void __launch_bounds__(256)
     col_reduce(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask,
                const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C, long rows_per_chunk,
-               double* __restrict__ part) {
+               double* __restrict__ part, const float* __restrict__ msc = nullptr, const float* __restrict__ msh = nullptr) {
   __shared__ double sm[256 * 8];
   const int t = threadIdx.x;
   const int Q = C >> 2, RL = 256 / Q;
   const int q = t % Q, rl = t / Q;
   double s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
   float mu[4] = {0, 0, 0, 0}, is[4] = {1, 1, 1, 1};
+  float ksc[4] = {0, 0, 0, 0}, ksh[4] = {0, 0, 0, 0};
   if (MODE == 1) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) { mu[j] = mean[q * 4 + j]; is[j] = invstd[q * 4 + j]; }
+    if (msc) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ksc[j] = msc[q * 4 + j]; ksh[j] = msh[q * 4 + j]; }
+    }
   }
   const long r0 = blockIdx.x * rows_per_chunk;
   const long r1 = min(M, r0 + rows_per_chunk);
@@ -61,6 +69,10 @@ __global__ void __launch_bounds__(256)
             if (!(yv4[u].y > 0.f)) g[1] = 0.f;
             if (!(yv4[u].z > 0.f)) g[2] = 0.f;
             if (!(yv4[u].w > 0.f)) g[3] = 0.f;
+          } else if (msc) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (!(fmaf(xv[j], ksc[j], ksh[j]) > 0.f)) g[j] = 0.f;
           }
 #pragma unroll
           for (int j = 0; j < 4; ++j) { s[j] += g[j]; ss[j] += (double)g[j] * ((xv[j] - mu[j]) * is[j]); }
@@ -186,15 +198,19 @@ __global__ void __launch_bounds__(256)
 __global__ void __launch_bounds__(256)
     bn_bwd_apply(const float* __restrict__ x, const float* dy, const float* __restrict__ ymask,
                  const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
-                 float* dx, float* gout, long nquad, int C) {
+                 float* dx, float* gout, long nquad, int C, const float* __restrict__ msc = nullptr,
+                 const float* __restrict__ msh = nullptr) {
   const bool fixed = (256 % (C >> 2)) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int c = (int)((i * 4) % C);
   float4 mu = ld4(mean, c), is = ld4(invstd, c), k0 = ld4(coef, c), k1 = ld4(coef + MAXC, c), k2 = ld4(coef + 2 * MAXC, c);
+  float4 ms = make_float4(0, 0, 0, 0), mh = ms;      // ReLU mask rebuilt from x (see col_reduce)
+  if (msc) { ms = ld4(msc, c); mh = ld4(msh, c); }
   for (; i < nquad; i += (long)gridDim.x * blockDim.x) {
     if (!fixed) {
       c = (int)((i * 4) % C);
       mu = ld4(mean, c); is = ld4(invstd, c); k0 = ld4(coef, c); k1 = ld4(coef + MAXC, c); k2 = ld4(coef + 2 * MAXC, c);
+      if (msc) { ms = ld4(msc, c); mh = ld4(msh, c); }
     }
     const float4 xv = reinterpret_cast<const float4*>(x)[i];
     const float4 d = reinterpret_cast<const float4*>(dy)[i];
@@ -205,6 +221,11 @@ __global__ void __launch_bounds__(256)
       if (!(y.y > 0.f)) g[1] = 0.f;
       if (!(y.z > 0.f)) g[2] = 0.f;
       if (!(y.w > 0.f)) g[3] = 0.f;
+    } else if (msc) {
+      if (!(fmaf(xv.x, ms.x, mh.x) > 0.f)) g[0] = 0.f;
+      if (!(fmaf(xv.y, ms.y, mh.y) > 0.f)) g[1] = 0.f;
+      if (!(fmaf(xv.z, ms.z, mh.z) > 0.f)) g[2] = 0.f;
+      if (!(fmaf(xv.w, ms.w, mh.w) > 0.f)) g[3] = 0.f;
     }
     const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
     const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, i4[4] = {is.x, is.y, is.z, is.w};

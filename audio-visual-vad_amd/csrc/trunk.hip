@@ -487,20 +487,25 @@ static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, cons
 }
 
 // BatchNorm backward of conv i:  dx = BN'(x_raw; dy masked by ymask>0); optional gout = masked dy
+// own_relu: this BatchNorm's output went straight through a ReLU (the first BN of a block): the mask is rebuilt from xraw
+// with the forward's saved scale / shift instead of reading the activation (ymask is then ignored)
 static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float* dy, const float* ymask, float* dx,
                        float* gout, long M, const avvad_trunk_params* prm, const avvad_trunk_grads* g,
-                       const avvad_trunk_desc* d, hipStream_t s) {
+                       const avvad_trunk_desc* d, hipStream_t s, bool own_relu = false) {
   const int C = p->conv[i].cout;
   StatCtx sc = stat_ctx(p, ws, M, C);
   const float* mean = ws + p->bn_mean + i * MAXC;
   const float* invstd = ws + p->bn_invstd + i * MAXC;
+  const float* msc = own_relu ? ws + p->bn_scale + i * MAXC : (const float*)nullptr;
+  const float* msh = own_relu ? ws + p->bn_shift + i * MAXC : (const float*)nullptr;
+  if (own_relu) ymask = nullptr;
   hipLaunchKernelGGL(col_reduce<1>, dim3(sc.nchunk), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, M, C,
-                     sc.rows_per_chunk, sc.part);
+                     sc.rows_per_chunk, sc.part, msc, msh);
   hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, FIN_CH)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], invstd,
                      d->training, g->bn_w[i], g->bn_b[i], ws + p->coef);
   const long nq = M * C / 4;
   hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid(nq)), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, ws + p->coef, dx, gout,
-                     nq, C);
+                     nq, C, msc, msh);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }
@@ -712,7 +717,7 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
       }
       if ((rc = wgrad(i2, ws + o[1], G1))) return rc;
       if ((rc = conv_dgrad(G1, ws + p.wd[i2], G2, p.geom[i2], 0, s, ws + p.slab))) return rc;  // d a1 in G2
-      if ((rc = bn_backward(&p, ws, i1, ws + o[0], G2, ws + o[1], G1, nullptr, M, prm, g, d, s))) return rc;  // d c1 in G1
+      if ((rc = bn_backward(&p, ws, i1, ws + o[0], G2, ws + o[1], G1, nullptr, M, prm, g, d, s, true))) return rc;  // d c1 in G1
       if ((rc = wgrad(i1, x, G1))) return rc;
       if ((rc = conv_dgrad(G1, ws + p.wd[i1], G3, p.geom[i1], 1, s, ws + p.slab))) return rc;  // d x += ...
       float* t = G0; G0 = G3; G3 = t;
