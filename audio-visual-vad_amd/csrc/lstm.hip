@@ -54,9 +54,10 @@ __global__ void lstm_gates_fwd(float* __restrict__ G, float* __restrict__ Cs, fl
 // The workgroup always runs 16 waves: B/16 sequence blocks x KS = 16/(B/16) K-slices (the loads are L2-latency-bound, so
 // a wave keeps 16 float4 loads in flight over a short slice instead of walking all of K); the slices' partial sums meet
 // in LDS and the slice-0 waves finish the step.
-// (Tried: ONE persistent launch per layer with the W_hh fragments resident in registers and a grid barrier per step --
-//  correct, but 0.4 ms/step SLOWER end to end: the per-step release/acquire fences that carry h_t across XCDs write back
-//  and invalidate the whole L2, which costs more than re-streaming W_hh from the Infinity Cache.  Also tried: the same
+// (Round 1 tried ONE persistent launch per layer with agent-scope release/acquire fences around a grid barrier: correct,
+//  0.4 ms/step SLOWER -- the fences write back and invalidate whole L2s every step.  Round 2's lstm_persistent_fwd below
+//  hands h_t over with write-through stores and a flag barrier instead and is the default where the shape allows; this
+//  kernel serves the other shapes and option lstm_no_persistent.  Also tried: the same
 //  skinny treatment for the backward product dh = dG W_hh (64 columns x a K-split per workgroup, slabs summed by the gate
 //  kernel): equal to the stream-K GEMM within 0.1 ms -- both stream all of W_hh every step.  Round 2 tried a fused backward
 //  step in this kernel's image -- W_hh transposed once, workgroup = 16 units x 64 sequences, dh in the accumulators, gate
@@ -142,6 +143,185 @@ __global__ void __launch_bounds__(1024)
     Cs[o] = c;
     y[o] = og * tanhf(c);
   }
+}
+
+// ------------------------------------------------------------------ persistent forward: ONE launch for steps 1 .. T-1
+// Grid = H/4 workgroups of 4 waves, all resident (a workgroup needs ~150 registers per lane and 4 KB of LDS: the chip
+// holds several per CU).  Workgroup blk owns hidden units 4 blk .. 4 blk + 3 for every sequence (B <= 64); wave w holds
+// the K quarter w of its 16 gate rows of W_hh as MFMA A fragments IN REGISTERS for the whole launch (NK float4 per lane),
+// so W_hh is read once per layer instead of once per step, and a step costs no launch.
+// What carries h_t between workgroups (per-XCD L2s are not coherent): h_t is stored with sc1 (write-through) stores and
+// read with sc1 (L1-bypassing) loads -- rows of y that nobody has read before, so no L2 holds an older copy -- and the
+// step barrier is one agent-scope atomic add per workgroup (behind s_waitcnt vmcnt(0) of every storing wave and a workgroup
+// barrier) polled by one lane with sc1 loads: MI355X_MICROARCH "Valid forms", first table row.  No agent-scope fences: the
+// release/acquire fences of round 1's persistent attempt wrote back and invalidated whole L2s every step and lost 0.4 ms.
+// Every spin is BOUNDED: if the grid ever failed to be co-resident the launch ends (status word set, results wrong and
+// loudly so) instead of hanging the device.
+template <int NK>   // H / 64: float4 fragments per lane and K quarter
+__global__ void __launch_bounds__(256)
+    lstm_persistent_fwd(float* __restrict__ G, float* __restrict__ Cs, float* __restrict__ y, const float* __restrict__ w_hh,
+                        const int* __restrict__ lengths, int B, int T, int H, unsigned* __restrict__ sync) {
+  __shared__ f32x4v part[4][4][64];      // [sequence group][K quarter][lane]
+  __shared__ int give_up;
+  const int lane = threadIdx.x & 63, ks = threadIdx.x >> 6;
+  const int i = lane & 15, q = lane >> 4;
+  const int blk = blockIdx.x, nblk = gridDim.x;      // nblk <= 256: one 16-byte poll per lane covers every flag
+  const int nsg = B >> 4;
+  const int kspan = H >> 2;
+  if (threadIdx.x == 0) give_up = 0;
+  // resident A fragments: row i = 4 u + gate  <->  W_hh row gate*H + 4 blk + u
+  f32x4v a[NK];
+  {
+    const float* wrow = w_hh + (long)((i & 3) * H + 4 * blk + (i >> 2)) * H + ks * kspan + 4 * q;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      const float4 v = *reinterpret_cast<const float4*>(wrow + 16 * kk);
+      a[kk] = f32x4v{v.x, v.y, v.z, v.w};
+    }
+  }
+  // the finishing wave of sequence group sg is wave sg: lane (i, q) owns (sequence 16 sg + i, unit 4 blk + q)
+  const int bfin = ks * 16 + i;
+  const bool fin = ks < nsg;
+  const int j = 4 * blk + q;
+  float cprev = fin ? Cs[((long)bfin * T + 0) * H + j] : 0.f;     // c_0 (written by lstm_gates_fwd before this launch)
+  const int len = fin ? lengths[bfin] : 0;
+  const __amdgpu_buffer_rsrc_t ry = brsrc2g(y);
+  const __amdgpu_buffer_rsrc_t rf = brsrc(reinterpret_cast<const float*>(sync + 64), nblk * 4);   // one flag word per workgroup
+  // The hand-off copy of h: hb[t & 1][b][H + 32].  In y a sequence's rows are T*H*4 bytes apart (64 KB at the bench shape):
+  // the 16 sequences of every load instruction, and every workgroup of an XCD at the same moment, fell on ONE L2 channel
+  // (the h reads + MFMAs of a step took 8.9 us for 3.4 us of MFMA).  Padded rows spread them over the channels.
+  const int LDHB = H + 32;
+  float* const hb = reinterpret_cast<float*>(sync + 1024);
+  const __amdgpu_buffer_rsrc_t rh = brsrc(hb, 2 * B * LDHB * 4);
+  // h_{t-1} of sequence group sg, this wave's K quarter: NK 16-byte sc1 loads (step 1 reads y[:, 0], written before the launch)
+  auto hload = [&](int sg, int t, f32x4v (&h)[NK]) {
+    if (t == 1) {
+      const int off = (int)((((long)(sg * 16 + i) * T) * H + ks * kspan + 4 * q) * 4);
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) h[kk] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(ry, off, 64 * kk, 16));
+    } else {
+      const int off = ((((t - 1) & 1) * B + sg * 16 + i) * LDHB + ks * kspan + 4 * q) * 4;
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) h[kk] = __builtin_bit_cast(f32x4v, __builtin_amdgcn_raw_buffer_load_b128(rh, off, 64 * kk, 16));
+    }
+  };
+  auto hmul = [&](const f32x4v (&h)[NK], int sg) {
+    // two accumulators: a dependent chain of this instruction issues every 40 cycles, independent ones every 32
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][0], h[kk][0], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][1], h[kk][1], acc1, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][2], h[kk][2], acc, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[kk][3], h[kk][3], acc1, 0, 0, 0);
+    }
+    acc[0] += acc1[0]; acc[1] += acc1[1]; acc[2] += acc1[2]; acc[3] += acc1[3];
+    part[sg][ks][lane] = acc;
+  };
+  __syncthreads();
+#ifdef AVVAD_LSTM_PROF
+  unsigned long long tA = 0, tB = 0, tC = 0;
+#endif
+  for (int t = 1; t < T; ++t) {
+#ifdef AVVAD_LSTM_PROF
+    const unsigned long long s0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    float gin[4] = {0.f, 0.f, 0.f, 0.f};
+    float* g = G + ((long)bfin * T + t) * 4 * H;
+    // two register sets: group sg+1's requests are in flight under group sg's MFMAs (one wave per SIMD: nothing else
+    // would hide them); sched_barriers keep hipcc from pairing each load with its four MFMAs
+    f32x4v h0[NK], h1[NK];
+    hload(0, t, h0);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int sg = 0; sg < nsg; sg += 2) {
+      if (sg + 1 < nsg) hload(sg + 1, t, h1);
+      else if (fin) {       // last group: this step's pre-activations ride under its MFMAs
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gin[e] = g[e * H + j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      hmul(h0, sg);
+      if (sg + 1 >= nsg) break;
+      if (sg + 2 < nsg) hload(sg + 2, t, h0);
+      else if (fin) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gin[e] = g[e * H + j];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      hmul(h1, sg + 1);
+    }
+#ifdef AVVAD_LSTM_PROF
+    const unsigned long long s1 = __builtin_amdgcn_s_memrealtime();
+#endif
+    __syncthreads();
+    if (fin) {
+      f32x4v r = part[ks][0][lane];
+#pragma unroll
+      for (int s2 = 1; s2 < 4; ++s2) {
+        const f32x4v pp = part[ks][s2][lane];
+        r[0] += pp[0]; r[1] += pp[1]; r[2] += pp[2]; r[3] += pp[3];
+      }
+      const long o = ((long)bfin * T + t) * H + j;
+      float hv = 0.f;
+      if (t < len) {
+        const float ig = sigmoidf_(gin[0] + r[0]), fg = sigmoidf_(gin[1] + r[1]), gg = tanhf(gin[2] + r[2]),
+                    og = sigmoidf_(gin[3] + r[3]);
+        const float c = fg * cprev + ig * gg;
+        hv = og * tanhf(c);
+        // h_t first (sc1: for every workgroup), then the layer's output and the state the backward reads
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, hv), rh, (((t & 1) * B + bfin) * LDHB + j) * 4, 0, 16);
+        y[o] = hv;
+        g[j] = ig; g[H + j] = fg; g[2 * H + j] = gg; g[3 * H + j] = og;
+        Cs[o] = c;
+        cprev = c;
+      } else {
+        __builtin_amdgcn_raw_buffer_store_b32(0, rh, (((t & 1) * B + bfin) * LDHB + j) * 4, 0, 16);
+        y[o] = 0.f;
+        g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f; g[3 * H + j] = 0.f;
+        Cs[o] = 0.f;
+        cprev = 0.f;
+      }
+    }
+    if (t + 1 == T) break;
+    // ---- step barrier: every storing wave drains, the workgroup meets, lane 0 publishes flag[blk] = t (sc1 store, no
+    // atomics: 256 adds onto one counter serialise, 6.6 us per step), wave 0 polls ALL flags with one 16-byte sc1 load per
+    // lane and joins the workgroup barrier only once every flag shows this step
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#ifdef AVVAD_LSTM_PROF
+    const unsigned long long s2 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (ks == 0 && !give_up) {
+      if (lane == 0) __builtin_amdgcn_raw_buffer_store_b32(t, rf, blk * 4, 0, 16);
+      int spins = 0;
+      for (;;) {
+        // lanes past the last flag read out of range = 0: treated as arrived
+        const i4v f = __builtin_amdgcn_raw_buffer_load_b128(rf, lane * 16, 0, 16);
+        const bool mine = (lane * 4 + 0 >= nblk || f[0] >= t) && (lane * 4 + 1 >= nblk || f[1] >= t) &&
+                          (lane * 4 + 2 >= nblk || f[2] >= t) && (lane * 4 + 3 >= nblk || f[3] >= t);
+        if (__all(mine)) break;
+        if (++spins > (1 << 21)) { if (lane == 0) { give_up = 1; sync[1] = 1u; } break; }       // never hang the device
+      }
+    }
+    __syncthreads();
+#ifdef AVVAD_LSTM_PROF
+    const unsigned long long s3 = __builtin_amdgcn_s_memrealtime();
+    tA += s1 - s0; tB += s2 - s1; tC += s3 - s2;
+#endif
+  }
+#ifdef AVVAD_LSTM_PROF
+  if (threadIdx.x == 0 && blk < 8) {
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(sync + 16) + 3 * blk;
+    o[0] = tA; o[1] = tB; o[2] = tC;
+  }
+#endif
+}
+
+// behind the persistent launch: had a step barrier ever timed out (status word set), the layer's output is poisoned
+// with NaNs -- a wrong result must not pass for a right one
+__global__ void lstm_persistent_check(const unsigned* __restrict__ sync, float* __restrict__ y, long n) {
+  if (sync[1] == 0u) return;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) y[i] = __builtin_nanf("");
 }
 
 // in: activated gates in G, dy[b][t], DH (recurrent dh from step t+1, consumed and zeroed), DC (dc from t+1)
@@ -276,6 +456,23 @@ extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const flo
   const int BG = B < 64 ? B : 64;
   const bool fused_step = (B == 16 || B == 32 || (B % 64 == 0 && B <= 65535 * 64)) && (H % (16 * (256 / BG)) == 0) &&
                           !avvad_tune().lstm_no_fused_step;
+  // ONE persistent launch for steps 1 .. T-1 (option lstm_no_persistent: the per-step kernels)
+  const int NKp = H / 64;
+  const bool persistent = fused_step && !avvad_tune().lstm_no_persistent && B <= 64 && B % 16 == 0 && T > 1 &&
+                          (NKp == 16 || NKp == 8 || NKp == 4) && H % 64 == 0 && H / 4 <= 256 &&
+                          (long)B * T * H * 4 < (1L << 31);
+  if (persistent) {
+    hipLaunchKernelGGL(lstm_gates_fwd, dim3(cdiv(B * H, 256)), dim3(256), 0, s, w.G, w.Cs, y, d->lengths, B, T, H, 0);
+    unsigned* sync = reinterpret_cast<unsigned*>(w.slab);          // the engine scratch is idle during the time loop
+    if (hipMemsetAsync(sync, 0, 2048, s) != hipSuccess) return AVVAD_ELAUNCH;   // status words + one flag per workgroup
+    // (behind them, from word 1024: the two padded hand-off copies of h, 2 x B x (H + 32) floats)
+    if (NKp == 16) hipLaunchKernelGGL(lstm_persistent_fwd<16>, dim3(H / 4), dim3(256), 0, s, w.G, w.Cs, y, w_hh, d->lengths, B, T, H, sync);
+    else if (NKp == 8) hipLaunchKernelGGL(lstm_persistent_fwd<8>, dim3(H / 4), dim3(256), 0, s, w.G, w.Cs, y, w_hh, d->lengths, B, T, H, sync);
+    else hipLaunchKernelGGL(lstm_persistent_fwd<4>, dim3(H / 4), dim3(256), 0, s, w.G, w.Cs, y, w_hh, d->lengths, B, T, H, sync);
+    hipLaunchKernelGGL(lstm_persistent_check, dim3(64), dim3(256), 0, s, sync, y, (long)B * T * H);
+    AVVAD_LAUNCH_CHECK();
+    return AVVAD_OK;
+  }
   for (int t = 0; t < T; ++t) {
     if (t > 0 && fused_step) {
       if (B >= 128 && H % 16 == 0)        // many sequences: one read of h_{t-1} serves 16 hidden units

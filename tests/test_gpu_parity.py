@@ -247,15 +247,21 @@ def test_lstm_full_size():
     _report("lstm 2x1024 In=768", y, ref, 1e-4)
 
 
-@pytest.mark.parametrize("B,H", [(16, 256), (32, 128), (64, 64), (128, 128), (192, 64), (256, 1024)])
-def test_lstm_fused_step_sequence_groups(B, H):
-    """The fused recurrent step (MFMA, one launch per time step) handles the batch in groups of min(B, 64) sequences:
-    BASELINE config 1's 256 sequences are four groups.  Ragged lengths, forward + backward against the oracle's time loop."""
+@pytest.mark.parametrize("B,H,per_step", [(16, 256, 0), (16, 256, 1), (32, 128, 0), (64, 64, 0), (128, 128, 0), (192, 64, 0),
+                                          (256, 1024, 0), (64, 1024, 0), (64, 1024, 1), (48, 512, 0), (32, 256, 0)])
+def test_lstm_fused_step_sequence_groups(B, H, per_step, lib_options):
+    """The recurrent forward: ONE persistent launch for all steps where the shape allows (B <= 64, H in {256, 512, 1024}:
+    h_t handed between workgroups by write-through stores and a flag barrier), else the fused step kernel (MFMA, one launch
+    per time step, the batch in groups of min(B, 64) sequences: BASELINE config 1's 256 sequences are four groups);
+    per_step=1 forces the step kernels on a persistent-eligible shape.  Ragged lengths, forward + backward against the
+    oracle's time loop."""
     from avvad import ops
     from oracle import head
     import torch.nn as nn
+    if per_step:
+        lib_options("lstm_no_persistent", 1)
     torch.manual_seed(B + H)
-    In, Tn = 40, 5 if H < 1024 else 3
+    In, Tn = 40, 5 if H < 1024 else (3 if B > 64 else 7)
     lstm = nn.LSTM(In, H, 1)
     x = torch.randn(B, Tn, In)
     lens = [int(v) for v in torch.randint(1, Tn + 1, (B,))]
