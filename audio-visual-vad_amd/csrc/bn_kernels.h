@@ -91,22 +91,31 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-// sum the per-chunk partials of channel c = blockIdx.x*FIN_CH + (tid % FIN_CH): 256/FIN_CH chunk-lanes per channel,
-// fixed order (deterministic); every thread of the 256-thread block must call it; lanes tid < FIN_CH get the totals.
-constexpr int FIN_CH = 8;    // channels per finalize block (grid = ceil(C / FIN_CH))
+// sum the per-chunk partials of channel c = blockIdx.x*FIN_CH + (tid % FIN_CH): 256/FIN_CH chunk-lanes per channel, each
+// adding its strided subset in order, then a fixed-shape pairwise tree in LDS (deterministic); every thread of the
+// 256-thread block must call it; lanes tid < FIN_CH get the totals.
+// (4 channels per block: the 40 finalize launches of a step are pure latency -- with 8 channels per block a 64-channel
+//  layer ran on 8 CUs, every lane walked ~30 dependent loads and one lane per channel then read 32 LDS words in series:
+//  9 us per launch, 0.36 ms per step.)
+constexpr int FIN_CH = 4;    // channels per finalize block (grid = ceil(C / FIN_CH))
 __device__ __forceinline__ void chunk_sums(const double* __restrict__ part, int nchunk, int C, double& s, double& ss) {
   constexpr int KL = 256 / FIN_CH;
   __shared__ double sm[2][KL][FIN_CH];
   const int cl = threadIdx.x % FIN_CH, kl = threadIdx.x / FIN_CH;
   const int c = blockIdx.x * FIN_CH + cl;
   double a = 0, b = 0;
-  if (c < C)
+  if (c < C) {
+#pragma unroll 4
     for (int i = kl; i < nchunk; i += KL) { a += part[((long)i * 2 + 0) * C + c]; b += part[((long)i * 2 + 1) * C + c]; }
+  }
   sm[0][kl][cl] = a; sm[1][kl][cl] = b;
   __syncthreads();
-  s = 0; ss = 0;
-  if (kl == 0)
-    for (int k = 0; k < KL; ++k) { s += sm[0][k][cl]; ss += sm[1][k][cl]; }
+#pragma unroll
+  for (int off = KL / 2; off > 0; off >>= 1) {
+    if (kl < off) { sm[0][kl][cl] += sm[0][kl + off][cl]; sm[1][kl][cl] += sm[1][kl + off][cl]; }
+    __syncthreads();
+  }
+  s = sm[0][0][cl]; ss = sm[1][0][cl];
 }
 
 // finalize batch statistics -> scale/shift (+ saved mean/invstd, running-stat update)
