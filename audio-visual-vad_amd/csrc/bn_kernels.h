@@ -7,7 +7,7 @@
 
 constexpr int BN_MAXC = 1024;
 constexpr int MAXC = BN_MAXC;
-constexpr int STAT_CHUNKS = 1024;   // workgroups of a column reduction (4 per CU)
+constexpr int STAT_CHUNKS = 512;    // workgroups of a column reduction (2 per CU; 1024 timed the same and doubled the finalize kernels' reads)
 
 // ------------------------------------------------------------------ column reductions ([M][C] fp32 -> per-channel fp64 sums)
 // MODE 0: sum x, sum x^2           (batch statistics)
