@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(256) chan_sum_acc(const float* __restrict__ dy
 //   dw[co][ci][k] += sum_{b,t} dy[b][co][t] x[b][ci][t + k]      db[co] += sum_{b,t} dy[b][co][t]
 // (the engine's 64x64 tile on this 32 x 2 product ran 168 us; this reads dy once at HBM rate)
 __global__ void __launch_bounds__(256)
-    narrow_conv1d_grads(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dw, float* __restrict__ db,
+    narrow_conv1d_grads(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ part,
                         int B, int Cout, int Cin, int Lout, int Lin, int fw) {
   __shared__ float sm[5][256];
   const int co = blockIdx.x, nw = Cin * fw;
@@ -118,8 +118,18 @@ __global__ void __launch_bounds__(256)
       for (int j = 0; j < 5; ++j) sm[j][threadIdx.x] += sm[j][threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x < nw && dw) atomicAdd(dw + (long)co * nw + threadIdx.x, sm[threadIdx.x][0]);
-  if (threadIdx.x == 0 && db) atomicAdd(db + co, sm[4][0]);
+  // partial sums of this (channel, sequence group); narrow_conv1d_grads_sum adds the groups in order (deterministic)
+  if (threadIdx.x < 5) part[((long)blockIdx.y * Cout + co) * 5 + threadIdx.x] = sm[threadIdx.x][0];
+}
+__global__ void narrow_conv1d_grads_sum(const float* __restrict__ part, int ny, int Cout, int nw, float* __restrict__ dw,
+                                        float* __restrict__ db) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * 5) return;
+  const int co = i / 5, j = i - co * 5;
+  float s = 0.f;
+  for (int y = 0; y < ny; ++y) s += part[((long)y * Cout + co) * 5 + j];
+  if (j < 4) { if (j < nw && dw) dw[(long)co * nw + j] += s; }
+  else if (db) db[co] += s;
 }
 
 __device__ __forceinline__ void pool_bin(int p, int Lv, int P, int& a, int& e) {
@@ -969,27 +979,51 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
     for (int r = 0; r < 16; ++r) bstore(accS[r], rd, offd, mfma32_row(r, 0) * rowV);
   }
+  // the four waves' sums meet in LDS in WAVE ORDER (plain adds between barriers, not LDS atomics in arrival order)
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
 #pragma unroll
-  for (int n = 0; n < NBT; ++n) {
+      for (int n = 0; n < NBT; ++n) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) atomicAdd(&red[(n * 32 + mfma32_row(r, lh)) * 32 + li], accW[n][r]);
-    atomicAdd(&red[Bn * 32 + n * 32 + li], bsum[n]);
+        for (int r = 0; r < 16; ++r) red[(n * 32 + mfma32_row(r, lh)) * 32 + li] += accW[n][r];
+      }
+      if (lh == 0) {
+#pragma unroll
+        for (int n = 0; n < NBT; ++n) red[Bn * 32 + n * 32 + li] += bsum[n];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lh == 1) {
+#pragma unroll
+        for (int n = 0; n < NBT; ++n) red[Bn * 32 + n * 32 + li] += bsum[n];
+      }
+    }
   }
   __syncthreads();
   float* out = slab + (long)blockIdx.x * SLAB;
   for (int i = threadIdx.x; i < SLAB; i += 256) out[i] = red[i];
 }
 
-// dW_b[bn][c] += sum_blocks slab[bn*32 + c]; db[bn] += slab[Bn*32 + bn]
+// dW_b[bn][c] += sum_blocks slab[bn*32 + c]; db[bn] += slab[Bn*32 + bn]   -- fixed order: 32 elements x 8 slab groups per
+// workgroup, ascending slabs inside a group, the groups combined in LDS in order (no atomics, see wn_wgrad_reduce_all)
 __global__ void __launch_bounds__(256)
     tail_wgrad_reduce(const float* __restrict__ slab, int nslab, int Bn, float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float sm[8][32];
   const int n = Bn * 32 + Bn;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + el;
   float sum = 0.f;
-  for (int b = blockIdx.y; b < nslab; b += gridDim.y) sum += slab[(long)b * n + i];
-  if (i < Bn * 32) { if (dW) atomicAdd(dW + i, sum); }
-  else if (db) atomicAdd(db + i - Bn * 32, sum);
+  if (i < n) {
+#pragma unroll 4
+    for (int b = grp; b < nslab; b += 8) sum += slab[(long)b * n + i];
+  }
+  sm[grp][el] = sum;
+  __syncthreads();
+  if (grp != 0 || i >= n) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) sum += sm[k][el];
+  if (i < Bn * 32) { if (dW) dW[i] += sum; }
+  else if (db) db[i - Bn * 32] += sum;
 }
 
 constexpr int WG_SLAB = 3 * 1024 + 64;   // per-workgroup partial sums of wn_block_wgrad_mfma
@@ -1404,18 +1438,42 @@ __global__ void __launch_bounds__(256, 2)
   for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
 }
 
-// dW_dil[d][c][k] += sum_blocks slab[k*1024 + d*32 + c]; dW_dense[r][d] += slab[2048 + r*32 + d]; biases likewise
-__global__ void __launch_bounds__(256)
-    wn_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restrict__ dW_dil, float* __restrict__ db_dil,
-                    float* __restrict__ dW_dense, float* __restrict__ db_dense) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= WG_SLAB) return;
+// dW_dil[d][c][k] += sum_blocks slab[k*1024 + d*32 + c]; dW_dense[r][d] += slab[2048 + r*32 + d]; biases likewise.
+// ALL residual blocks in one launch behind the last of them (blockIdx.y = layer; 20 launches of ~5 us before), and in a
+// FIXED order: 32 elements x 8 slab groups per workgroup, each thread adds its group's slabs in ascending order, the eight
+// partial sums meet in LDS in group order, one thread adds the total onto the gradient.  (The per-layer version spread
+// the slabs over gridDim.y and added with float atomics: the last place where the encoder's weight gradients could
+// differ in the last bit from run to run.)
+constexpr int WN_MAXL = 64;       // residual blocks one reduce launch covers
+struct WgradTab {
+  const float* slab[WN_MAXL];
+  int nslab[WN_MAXL];
+  float* dW_dil[WN_MAXL];
+  float* db_dil[WN_MAXL];
+  float* dW_dense[WN_MAXL];
+  float* db_dense[WN_MAXL];
+};
+__global__ void __launch_bounds__(256) wn_wgrad_reduce_all(const WgradTab tab) {
+  __shared__ float sm[8][32];
+  const int l = blockIdx.y;
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + el;                     // WG_SLAB = 98 * 32
+  const int nslab = tab.nslab[l];
   float s = 0.f;
-  for (int b = blockIdx.y; b < nslab; b += gridDim.y) s += slab[(long)b * WG_SLAB + i];   // gridDim.y partial sums
-  if (i < 2048) { if (dW_dil) atomicAdd(dW_dil + (i & 1023) * 2 + (i >> 10), s); }   // every pointer may be NULL (frozen)
-  else if (i < 3072) { if (dW_dense) atomicAdd(dW_dense + i - 2048, s); }
-  else if (i < 3104) { if (db_dil) atomicAdd(db_dil + i - 3072, s); }
-  else if (db_dense) atomicAdd(db_dense + i - 3104, s);
+  if (nslab > 0) {
+    const float* sl = tab.slab[l] + i;
+#pragma unroll 4
+    for (int b = grp; b < nslab; b += 8) s += sl[(long)b * WG_SLAB];
+  }
+  sm[grp][el] = s;
+  __syncthreads();
+  if (grp != 0 || nslab <= 0) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s += sm[k][el];
+  if (i < 2048) { if (tab.dW_dil[l]) tab.dW_dil[l][(i & 1023) * 2 + (i >> 10)] += s; }   // every pointer may be NULL (frozen)
+  else if (i < 3072) { if (tab.dW_dense[l]) tab.dW_dense[l][i - 2048] += s; }
+  else if (i < 3104) { if (tab.db_dil[l]) tab.db_dil[l][i - 3072] += s; }
+  else if (tab.db_dense[l]) tab.db_dense[l][i - 3104] += s;
 }
 
 // ------------------------------------------------------------------ plan / workspace
@@ -1450,7 +1508,8 @@ static int make_plan(const avvad_wavenet_desc* d, Plan* p) {
       for (int i = 0; i < p->n; ++i) p->zs[i] = zb;
     }
     {   // weight-gradient slabs: residual blocks (WG_MAXBLK x WG_SLAB) or the tail (256 workgroups x (Bn*32 + Bn))
-      const size_t a = (size_t)WG_MAXBLK * WG_SLAB, b2 = (size_t)256 * ((size_t)d->Bn * 33);
+      const bool perlayer = d->R == 32 && d->D == 32 && d->fw == 2;      // one slab set per residual block: ONE reduce launch
+      const size_t a = (size_t)WG_MAXBLK * WG_SLAB * (perlayer ? (size_t)p->n : 1), b2 = (size_t)256 * ((size_t)d->Bn * 33);
       p->slab = take(a > b2 ? a : b2);
     }
     p->gslab = take(igemm::SLAB_FLOATS);
@@ -1634,7 +1693,7 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     }
     hipLaunchKernelGGL(tail_bwd_wgrad_mfma<8>, dim3((int)blocks), dim3(256), lds, s, ws + p.s[p.n], prm->bott_w,
                        d->use_bias ? prm->bott_b : (const float*)nullptr, dout, GA, ws + p.slab, B, Lv, d->P);
-    hipLaunchKernelGGL(tail_wgrad_reduce, dim3(cdiv(Bn * 33, 256), 16), dim3(256), 0, s, ws + p.slab, (int)blocks, Bn, g->bott_w,
+    hipLaunchKernelGGL(tail_wgrad_reduce, dim3(cdiv(Bn * 33, 32)), dim3(256), 0, s, ws + p.slab, (int)blocks, Bn, g->bott_w,
                        d->use_bias ? g->bott_b : (float*)nullptr);
   } else if (tail_mfma) {
     long blocks = ((long)B * cdiv(Lv, 32) + 3) / 4;
@@ -1653,7 +1712,21 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     hipLaunchKernelGGL(conv1d_bwd_data_generic, dim3(grid1((long)B * R * Lv)), dim3(256), 0, s, DZT, prm->bott_w,
                        (const float*)nullptr, (const float*)nullptr, GA, B, R, Bn, Lv, Lv, 1, 1, 0, 0);
   // ---- residual blocks, last to first
+  WgradTab wtab;
+  bool any_slab = false;
+  for (int l = 0; l < WN_MAXL; ++l) {
+    wtab.slab[l] = nullptr; wtab.nslab[l] = 0;
+    wtab.dW_dil[l] = wtab.db_dil[l] = wtab.dW_dense[l] = wtab.db_dense[l] = nullptr;
+  }
+  auto note_slabs = [&](int i, float* slab_i, long wb) {
+    wtab.slab[i] = slab_i; wtab.nslab[i] = (int)wb;
+    wtab.dW_dil[i] = g->dil_w_h[i]; wtab.dW_dense[i] = g->dense_w_h[i];
+    wtab.db_dil[i] = d->use_bias ? g->dil_b_h[i] : (float*)nullptr;
+    wtab.db_dense[i] = d->use_bias ? g->dense_b_h[i] : (float*)nullptr;
+    any_slab = true;
+  };
   for (int i = p.n - 1; i >= 0; --i) {
+    float* const slab_i = ws + p.slab + (size_t)i * WG_MAXBLK * WG_SLAB;     // this block's partial sums (reduced at the end)
     const int dil = d->dilations_h[i];
     const int Li = p.L[i], Lo = p.L[i + 1];
     const float* si = ws + p.s[i];
@@ -1679,18 +1752,16 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
         if (wb < 1) wb = 1;
         if (!avvad_tune().wn_bwd_t) {
           hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd,
-                             prm->dense_w_h[i], si, DZ, ws + p.slab, B, Li, dil);
+                             prm->dense_w_h[i], si, DZ, slab_i, B, Li, dil);
         } else {
           // alternate: transposed-product form, under 256 registers, two workgroups per CU (one wave per SIMD each)
           wb = ((long)B * cdiv(Lo, 32) + 15) / 16;
           if (wb > 512) wb = 512;
           if (wb < 1) wb = 1;
           hipLaunchKernelGGL(wn_block_bwd_dzw_t, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd, prm->dense_w_h[i], si,
-                             DZ, ws + p.slab, B, Li, dil);
+                             DZ, slab_i, B, Li, dil);
         }
-        hipLaunchKernelGGL(wn_wgrad_reduce, dim3(cdiv(WG_SLAB, 256), 32), dim3(256), 0, s, ws + p.slab, (int)wb, g->dil_w_h[i],
-                           d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
-                           d->use_bias ? g->dense_b_h[i] : (float*)nullptr);
+        note_slabs(i, slab_i, wb);
       } else {
         // (frozen weights / tuning switch) separate kernels: z is not kept by the forward -> rebuild it first
         long fb = blocks > 512 ? 512 : blocks;
@@ -1702,10 +1773,8 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
           long wb = ((long)B * cdiv(Lo, 32) + 15) / 16;   // >= 4 tiles per wave
           if (wb > WG_MAXBLK) wb = WG_MAXBLK;
           if (wb < 1) wb = 1;
-          hipLaunchKernelGGL(wn_block_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, DZ, si, ws + p.slab, B, Li, dil);
-          hipLaunchKernelGGL(wn_wgrad_reduce, dim3(cdiv(WG_SLAB, 256), 32), dim3(256), 0, s, ws + p.slab, (int)wb, g->dil_w_h[i],
-                             d->use_bias ? g->dil_b_h[i] : (float*)nullptr, g->dense_w_h[i],
-                             d->use_bias ? g->dense_b_h[i] : (float*)nullptr);
+          hipLaunchKernelGGL(wn_block_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, Zi, DZ, si, slab_i, B, Li, dil);
+          note_slabs(i, slab_i, wb);
         }
       }
       blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
@@ -1735,11 +1804,17 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     }
     float* t = GA; GA = GB; GB = t;
   }
+  if (any_slab) hipLaunchKernelGGL(wn_wgrad_reduce_all, dim3(WG_SLAB / 32, p.n), dim3(256), 0, s, wtab);
   // ---- causal layer
   if (d->qc * fw <= 4) {   // narrow causal layer: weight + bias gradient in one pass over GA
     if (g->causal_w || (d->use_bias && g->causal_b))
-      hipLaunchKernelGGL(narrow_conv1d_grads, dim3(R, B < 32 ? B : 32), dim3(256), 0, s, GA, wave, g->causal_w,
-                         d->use_bias ? g->causal_b : (float*)nullptr, B, R, d->qc, p.L[0], d->L, fw);
+    {
+      const int ny = B < 32 ? B : 32;
+      float* part = ws + p.gslab;          // the engine scratch is idle here
+      hipLaunchKernelGGL(narrow_conv1d_grads, dim3(R, ny), dim3(256), 0, s, GA, wave, part, B, R, d->qc, p.L[0], d->L, fw);
+      hipLaunchKernelGGL(narrow_conv1d_grads_sum, dim3(cdiv(R * 5, 256)), dim3(256), 0, s, part, ny, R, d->qc * fw, g->causal_w,
+                         d->use_bias ? g->causal_b : (float*)nullptr);
+    }
   } else {
     if (g->causal_w && (rc = wgrad_conv1d(GA, wave, g->causal_w, B, R, d->qc, p.L[0], d->L, fw, 1, 0, s, ws + p.gslab))) return rc;
     if (d->use_bias) bias_grad(GA, g->causal_b, B, R, p.L[0], s);

@@ -196,6 +196,30 @@ def test_wavenet_golden(name, alt, lib_options):
         _report_grad(name + " d/d" + k, p.grad, g["g." + k])
 
 
+def test_wavenet_backward_is_bit_reproducible():
+    """Two runs of the encoder's forward + backward on the same inputs give the SAME BITS in every gradient: the residual
+    blocks' and the tail's weight-gradient partial sums meet in fixed order (wave-ordered LDS adds, slab reductions without
+    atomics), like the engine's stream-K fix-up."""
+    from packages.models.wavenet_autoencoder import wavenet_autoencoder
+    cfg = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in range(10)] * 2, en_residual_channel=32,
+               en_dilation_channel=32, en_bottleneck_width=256, en_pool_kernel_size=16, use_bias=True)
+    torch.manual_seed(7)
+    m = wavenet_autoencoder(**cfg).to(DEV)
+    x = (torch.rand(24, 1, 6143, device=DEV) * 2 - 1).requires_grad_(True)
+    Gd = torch.randn(24, 256, 16, device=DEV)
+    runs = []
+    for _ in range(3):
+        for p in m.parameters():
+            p.grad = None
+        x.grad = None
+        (m(x) * Gd).sum().backward()
+        torch.cuda.synchronize()
+        runs.append([x.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+    for r in runs[1:]:
+        for a, b in zip(runs[0], r):
+            assert torch.equal(a, b)
+
+
 def test_wavenet_batch_and_tails():
     """ragged tile tails (L not a multiple of 32) and B>1 on the MFMA block path vs the oracle."""
     from oracle import wavenet as ow
