@@ -641,6 +641,40 @@ def test_training_steps_match_cpu_adam():
     assert p0.grad.data_ptr() >= opt.flat_grad.data_ptr() and p0.grad.data_ptr() < opt.flat_grad.data_ptr() + 4 * opt.flat_grad.numel()
 
 
+def test_av_training_is_bit_reproducible():
+    """Two trainings from the same initial state (W0 encoder, ResNet-18 trunk, 2 x LSTM(1024), FC; 16 sequences x 16
+    frame-pairs; 2 Adam steps, the encoder on its side stream) end in the SAME BITS: no kernel of the step adds in arrival
+    order (stream-K fix-up, BatchNorm's two-stage sums, the encoder's slab reductions, one-block loss)."""
+    import copy
+    from avvad.optim import FlatAdam
+    from packages.models.AV_Net import DeepVAD_AV
+    from packages.models.utils import batch_binary_cross_entropy
+    wcfg = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in range(10)] * 2, en_residual_channel=32,
+                en_dilation_channel=32, en_bottleneck_width=256, en_pool_kernel_size=16, use_bias=True)
+    torch.manual_seed(3)
+    m0 = DeepVAD_AV(2, 1024, 1, wavenet_params=wcfg)
+    B, Tn = 16, 16
+    wave = (torch.rand(B, 1, Tn * 256 + 2047) * 2 - 1).to(DEV)
+    video = torch.randn(B, Tn, 67, 67).to(DEV)
+    tgt = (torch.rand(B, Tn, 1) > 0.5).float().to(DEV)
+    lens = torch.randint(3, Tn + 1, (B,))
+    lens[0] = Tn
+    finals = []
+    for run in range(2):
+        m = copy.deepcopy(m0).to(DEV).train()
+        opt = FlatAdam(m.parameters(), lr=1e-3, betas=(0.9, 0.999))
+        for step in range(2):
+            loss = batch_binary_cross_entropy(m(wave, video, lens), tgt, lens.tolist(), 1e-8)
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
+        torch.cuda.synchronize()
+        finals.append(([p.detach().clone() for p in m.parameters()] + [b.detach().clone() for b in m.buffers()], float(loss.detach())))
+    assert finals[0][1] == finals[1][1]
+    for a, b in zip(finals[0][0], finals[1][0]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("L", [16000, 16001, 4096 + 768])
 def test_stft_frontend_gpu(L):
     """GPU STFT (framing + Hann + DFT as one MFMA GEMM) vs the oracle restatement of stft_pytorch (torch.stft on the
