@@ -15,11 +15,13 @@ constexpr int STAT_CHUNKS = 512;    // workgroups of a column reduction (2 per C
 //         msc/msh (instead of ymask): the ReLU mask of a BatchNorm whose output went straight into a ReLU is rebuilt from x
 //         itself, fmaf(x, msc[c], msh[c]) > 0 -- the forward's own expression on the saved scale/shift, so the same bits --
 //         and the activation tensor is not read at all (one of the three planes this pass streams)
+//         qmask (instead of ymask): one byte per quad written by bn_act, bit j = (y[j] > 0)
 template <int MODE>
 __global__ void __launch_bounds__(256)
     col_reduce(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ ymask,
                const float* __restrict__ mean, const float* __restrict__ invstd, long M, int C, long rows_per_chunk,
-               double* __restrict__ part, const float* __restrict__ msc = nullptr, const float* __restrict__ msh = nullptr) {
+               double* __restrict__ part, const float* __restrict__ msc = nullptr, const float* __restrict__ msh = nullptr,
+               const unsigned char* __restrict__ qmask = nullptr) {
   __shared__ double sm[256 * 8];
   const int t = threadIdx.x;
   const int Q = C >> 2, RL = 256 / Q;
@@ -43,6 +45,7 @@ __global__ void __launch_bounds__(256)
   if (rl < RL)
     for (long r = r0 + rl; r < r1; r += (long)U * RL) {
       float4 xv4[U], dv4[U], yv4[U];
+      unsigned qm[U];
       bool live[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -53,6 +56,7 @@ __global__ void __launch_bounds__(256)
         if (MODE == 1) {
           dv4[u] = *reinterpret_cast<const float4*>(dy + o);
           if (ymask) yv4[u] = *reinterpret_cast<const float4*>(ymask + o);
+          else if (qmask) qm[u] = qmask[o >> 2];
         }
       }
 #pragma unroll
@@ -69,6 +73,10 @@ __global__ void __launch_bounds__(256)
             if (!(yv4[u].y > 0.f)) g[1] = 0.f;
             if (!(yv4[u].z > 0.f)) g[2] = 0.f;
             if (!(yv4[u].w > 0.f)) g[3] = 0.f;
+          } else if (qmask) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+              if (!((qm[u] >> j) & 1u)) g[j] = 0.f;
           } else if (msc) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -176,7 +184,7 @@ __device__ __forceinline__ float4 ld4(const float* p, int c) { return *reinterpr
 __global__ void __launch_bounds__(256)
     bn_act(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
            const float* __restrict__ idn, const float* __restrict__ iscale, const float* __restrict__ ishift,
-           float* __restrict__ y, long nquad, int C, int relu) {
+           float* __restrict__ y, long nquad, int C, int relu, unsigned char* __restrict__ qmask_out = nullptr) {
   const bool fixed = (256 % (C >> 2)) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int c = (int)((i * 4) % C);
@@ -199,6 +207,9 @@ __global__ void __launch_bounds__(256)
     }
     if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
     reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    // the ReLU mask of this quad as one byte (bit j: y[j] > 0): what the backward reads instead of y (1/16 of its bytes)
+    if (qmask_out)
+      qmask_out[i] = (unsigned char)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
   }
 }
 
@@ -208,7 +219,7 @@ __global__ void __launch_bounds__(256)
     bn_bwd_apply(const float* __restrict__ x, const float* dy, const float* __restrict__ ymask,
                  const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
                  float* dx, float* gout, long nquad, int C, const float* __restrict__ msc = nullptr,
-                 const float* __restrict__ msh = nullptr) {
+                 const float* __restrict__ msh = nullptr, const unsigned char* __restrict__ qmask = nullptr) {
   const bool fixed = (256 % (C >> 2)) == 0;
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   int c = (int)((i * 4) % C);
@@ -230,6 +241,12 @@ __global__ void __launch_bounds__(256)
       if (!(y.y > 0.f)) g[1] = 0.f;
       if (!(y.z > 0.f)) g[2] = 0.f;
       if (!(y.w > 0.f)) g[3] = 0.f;
+    } else if (qmask) {
+      const unsigned qm = qmask[i];
+      if (!(qm & 1u)) g[0] = 0.f;
+      if (!(qm & 2u)) g[1] = 0.f;
+      if (!(qm & 4u)) g[2] = 0.f;
+      if (!(qm & 8u)) g[3] = 0.f;
     } else if (msc) {
       if (!(fmaf(xv.x, ms.x, mh.x) > 0.f)) g[0] = 0.f;
       if (!(fmaf(xv.y, ms.y, mh.y) > 0.f)) g[1] = 0.f;
