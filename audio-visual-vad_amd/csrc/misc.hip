@@ -31,7 +31,7 @@ const OptName kOpts[] = {
 int parse_opt(const char* name, const char* v) {
   if (!strcmp(name, "igemm_variant")) return v[0] == 'd' ? 0 : (v[0] == 's' ? 1 : (v[0] == 'w' ? 2 : atoi(v)));
   if (!strcmp(name, "no_streamk")) return v[0] == 'a' ? 1 : (v[0] >= '0' && v[0] <= '9' && !v[1] ? 10 + (v[0] - '0') : atoi(v));
-  if (!strcmp(name, "max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid") || !strcmp(name, "wn_dx")) return atoi(v);
+  if (!strcmp(name, "max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid") || !strcmp(name, "wn_dx") || !strcmp(name, "wn_bwd_t")) return atoi(v);
   return (v[0] && strcmp(v, "0")) ? 1 : 0;
 }
 }  // namespace

@@ -1291,6 +1291,151 @@ __global__ void __launch_bounds__(256)
   for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
 }
 
+// HIGH-OCCUPANCY form of the fused pass (option wn_bwd_t = 2): weights read from LDS per MFMA, no cross-tile prefetch -> under
+// 256 registers, two waves per SIMD (two workgroups per CU).
+__global__ void __launch_bounds__(256, 2)
+    wn_block_bwd_dz_wgrad_occ(const float* __restrict__ dS, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
+                               const float* __restrict__ w_dense, const float* __restrict__ s_in, float* __restrict__ DZ,
+                               float* __restrict__ slab, int B, int Lin, int dil) {
+  __shared__ float tile[4][2][32 * 33];
+  __shared__ float red[3 * 1024 + 64];
+  __shared__ float wl[32 * 65 + 32];
+  __shared__ float wtl[32 * 33];        // W_dense[r][d], padded rows: A[i = d = li][k = r = 2s+lh] = wtl[(2s+lh)*33 + li]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const int ntiles = B * tiles_per_seq;
+  float* T = tile[wave][0];
+  float* Th = tile[wave][lh];           // this lane half's tile for the two-tap transpose
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  if (threadIdx.x < 32) wl[2080 + threadIdx.x] = b_dil ? b_dil[threadIdx.x] : 0.f;
+  for (int i = threadIdx.x; i < 1024; i += 256) wtl[(i >> 5) * 33 + (i & 31)] = w_dense[i];
+  for (int i = threadIdx.x; i < 3 * 1024 + 64; i += 256) red[i] = 0.f;
+  __syncthreads();
+  const float* wtp = wtl + lh * 33 + li;       // + 66 s
+  const float* wdp = wl + li * 65 + lh;        // + 2 s: W_dil[d = li][c = s][tap = lh]  (the forward's fragment)
+  const float* bzl = wl + 2080 + 4 * lh;
+  __builtin_amdgcn_wave_barrier();
+
+  f32x16 acc0, acc1, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; acc2[r] = 0.f; }
+  float bs_dz = 0.f, bs_ds = 0.f;
+  const int rowL = Lin * 4, rowO = Lo * 4;
+
+  // One wave per SIMD is resident (368 registers), so VALU instructions add to the 96 MFMAs of a tile one for one (~4
+  // cycles each): the flat-addressed version of this kernel carried 1225 of them per tile -- 64-bit address arithmetic
+  // for 64 memory instructions, a validity select on every loaded value, two-instruction ReLUs.  Buffer addressing
+  // (common.h): samples past the end of a sequence carry an out-of-range offset, their loads return 0 and their stores are
+  // dropped; a zero dS column makes every product of that column zero, so nothing downstream needs masking.
+  // Software pipeline across tiles: the NEXT tile's 48 loads are issued before this tile's 96 MFMAs and LDS transposes
+  // (nothing else hides their latency), alternating between two register sets instead of copying.
+  auto issue = [&](int tile, float (&gn)[16], float (&xn)[32]) {
+    const int tc = tile < ntiles ? tile : ntiles - 1;
+    const int b = tc / tiles_per_seq;
+    const int t = (tc - b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lo;
+    const __amdgpu_buffer_rsrc_t rg = brsrc(dS + (long)b * 32 * Lo, 32 * rowO);
+    const __amdgpu_buffer_rsrc_t rx = brsrc(s_in + (long)b * 32 * Lin, 32 * rowL);
+    const int offg = ok ? t * 4 + lh * rowO : BUF_OOB;
+    const int offx = ok ? (t + lh * dil) * 4 : BUF_OOB;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gn[q] = bload(rg, offg, 2 * q * rowO);
+#pragma unroll
+    for (int c = 0; c < 32; ++c) xn[c] = bload(rx, offx, c * rowL);
+  };
+  auto compute = [&](int tidx, const float (&g)[16], const float (&xraw)[32]) {
+    const int b = tidx / tiles_per_seq;
+    const int t = (tidx - b * tiles_per_seq) * 32 + li;
+    const int offo = t < Lo ? t * 4 + 4 * lh * rowO : BUF_OOB;
+    const __amdgpu_buffer_rsrc_t rz = brsrc(DZ + (long)b * 32 * Lo, 32 * rowO);
+    float x[32];
+#pragma unroll
+    for (int c = 0; c < 32; ++c) x[c] = relu1(xraw[c]);      // relu(s tap lh); 0 outside the sequence
+    // z exactly as the forward builds it
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = bzl[mfma32_row(r, 0)];
+#pragma unroll
+    for (int s = 0; s < 32; ++s) z = mfma32(wdp[2 * s], x[s], z);
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc = mfma32(wtp[66 * q], g[q], acc);
+    float f0[16], f1[16];
+    // ---- dz (D layout: rows mfma32_row(r, lh), column = time li) -> store, transpose
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float dz = z[r] > 0.f ? acc[r] : 0.f;            // (a column past the sequence has dS = 0, so acc = 0)
+      bstore(dz, rz, offo, mfma32_row(r, 0) * rowO);
+      T[mfma32_row(r, lh) * 33 + li] = dz;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { f0[q] = T[li * 33 + 2 * q + lh]; bs_dz += f0[q]; }   // f0 = dz[d = li][t = 2q+lh]
+    __builtin_amdgcn_wave_barrier();
+    // ---- both taps of relu(s): lane half h writes its 32 channels into tile h
+#pragma unroll
+    for (int c = 0; c < 32; ++c) Th[c * 33 + li] = x[c];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) f1[q] = tile[wave][0][li * 33 + 2 * q + lh];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc0 = mfma32(f0[q], f1[q], acc0);
+#pragma unroll
+    for (int q = 0; q < 16; ++q) f1[q] = tile[wave][1][li * 33 + 2 * q + lh];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc1 = mfma32(f0[q], f1[q], acc1);
+    __builtin_amdgcn_wave_barrier();
+    // ---- dS (channel 2q+lh on register q) and relu(z) (D layout; multiplied by dS = 0 past the sequence)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) T[(2 * q + lh) * 33 + li] = g[q];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[wave][1][mfma32_row(r, lh) * 33 + li] = relu1(z[r]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { f0[q] = T[li * 33 + 2 * q + lh]; bs_ds += f0[q]; }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) f1[q] = tile[wave][1][li * 33 + 2 * q + lh];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc2 = mfma32(f0[q], f1[q], acc2);
+    __builtin_amdgcn_wave_barrier();
+  };
+  const TileWalk tw = xcd_walk(ntiles);
+  const int first = __builtin_amdgcn_readfirstlane((int)tw.first), last = (int)tw.last, stride = (int)tw.stride;
+  for (int tl = first; tl < last; tl += stride) {       // nothing held across tiles: the other wave of the SIMD hides the loads
+    float ga[16], xa[32];
+    issue(tl, ga, xa);
+    __builtin_amdgcn_sched_barrier(0);
+    compute(tl, ga, xa);
+  }
+
+  // the four waves' sums meet in LDS in WAVE ORDER (plain adds between barriers: float atomics here added them in
+  // arrival order, the one place left where this kernel's result could differ in the last bit from run to run)
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mfma32_row(r, lh);
+        red[row * 32 + li] += acc0[r];
+        red[1024 + row * 32 + li] += acc1[r];
+        red[2048 + row * 32 + li] += acc2[r];
+      }
+      // the bias sums: both lane halves hold partial sums of the same 32 channels -> half 0 first, then half 1
+      if (lh == 0) { red[3072 + li] += bs_dz; red[3104 + li] += bs_ds; }
+      __builtin_amdgcn_wave_barrier();
+      if (lh == 1) { red[3072 + li] += bs_dz; red[3104 + li] += bs_ds; }
+    }
+  }
+  __syncthreads();
+  float* out = slab + (long)blockIdx.x * WG_SLAB;
+  for (int i = threadIdx.x; i < WG_SLAB; i += 256) out[i] = red[i];
+}
+
 // ------------------------------------------------------------------ the same pass with TRANSPOSED products: no LDS transposes
 // wn_block_bwd_dz_wgrad_mfma pushes five 32x32 tiles per time tile through LDS to turn "time on the lane" (how the data
 // lies in memory) into "channel on the lane" (what a contraction over TIME wants), holds 368 registers and runs one wave
@@ -1750,8 +1895,19 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
         if (wb > 256) wb = 256;
         if (wb > WG_MAXBLK) wb = WG_MAXBLK;
         if (wb < 1) wb = 1;
-        if (!avvad_tune().wn_bwd_t) {
+        // option wn_bwd_t: 0 by the descriptor's shared_device hint, 1 transposed-product alternate, 2 high-occupancy form,
+        // 3 resident-weights form.  Alone on the device the two-waves-per-SIMD form wins (encoder fwd+bwd 3.09 -> 2.90 ms);
+        // beside the trunk's backward on the other stream it costs the STEP 0.25 ms (same-process A/B), like the dx kernel.
+        const int bt = avvad_tune().wn_bwd_t == 0 ? (d->shared_device ? 3 : 2) : avvad_tune().wn_bwd_t;
+        if (bt == 3) {
           hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_mfma, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd,
+                             prm->dense_w_h[i], si, DZ, slab_i, B, Li, dil);
+        } else if (bt == 2) {
+          wb = ((long)B * cdiv(Lo, 32) + 15) / 16;
+          if (wb > 512) wb = 512;
+          if (wb >= 8) wb = wb / 8 * 8;
+          if (wb < 1) wb = 1;
+          hipLaunchKernelGGL(wn_block_bwd_dz_wgrad_occ, dim3((int)wb), dim3(256), 0, s, GA, prm->dil_w_h[i], bd,
                              prm->dense_w_h[i], si, DZ, slab_i, B, Li, dil);
         } else {
           // alternate: transposed-product form, under 256 registers, two workgroups per CU (one wave per SIMD each)

@@ -46,7 +46,7 @@ int avvad_abi_version(void);
  *   "no_buf" (1 = convolution gathers with flat addressing + validity selects, the form operands >= 2 GiB use),
  *   "lstm_no_fused_step", "lstm_no_persistent", "wn_no_fused_tail", "wn_no_fused_wgrad", "wn_bwd_t",
  *   "wn_flat" (encoder block forward: 0 by plane length, 1 flat dword kernel, 2 buffer dword kernel with resident
- *   weights, 3 dwordx4 kernel, 4 high-occupancy kernel), "wn_dx" (0 by the descriptor's shared_device hint, 1 / 2 force
+ *   weights, 3 dwordx4 kernel, 4 high-occupancy kernel), "wn_dx" / "wn_bwd_t" (0 by the descriptor's shared_device hint, other values force
  *   a form), "wn_grid" (workgroup cap of the encoder block kernels),
  *   "bf16" (bf16-input MFMA with fp32 accumulation for the trunk convolutions and the dense GEMMs -- BASELINE config 5's
  *   mixed precision; storage, BatchNorm statistics, LSTM cell, loss and Adam stay fp32; never the default),

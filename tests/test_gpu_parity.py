@@ -169,11 +169,11 @@ def test_engine_cu_cap_option(lib_options):
 # ------------------------------------------------------------------------------------------ WaveNet encoder
 @pytest.mark.parametrize("name,alt", [("wn_tiny", 0), ("wn_fw3_qc2", 0), ("wn_nobias", 0), ("wn_w0", 0), ("wn_w0_t16", 0),
                                       ("wn_nobias", 1), ("wn_w0", 1), ("wn_w0_t16", 1), ("wn_w0", 2), ("wn_w0_t16", 2),
-                                      ("wn_nobias", 3), ("wn_w0", 3)])
+                                      ("wn_nobias", 3), ("wn_w0", 3), ("wn_nobias", 4), ("wn_w0", 4), ("wn_w0_t16", 4)])
 def test_wavenet_golden(name, alt, lib_options):
     """alt=1: the alternate block backward kept in the library (transposed products, no LDS transposes); alt=2: the kernel
     forms picked beside another stream (dx with resident weights, forward with resident weights + cross-tile prefetch);
-    alt=3: round 1's flat-addressed kernels."""
+    alt=3: round 1's flat-addressed kernels; alt=4: the resident-weights form of the fused block backward (the default is the high-occupancy one when the device is ours)."""
     from packages.models.wavenet_autoencoder import wavenet_autoencoder
     if alt == 1:
         lib_options("wn_bwd_t", 1)
@@ -182,6 +182,8 @@ def test_wavenet_golden(name, alt, lib_options):
         lib_options("wn_flat", 2)
     elif alt == 3:
         lib_options("wn_flat", 1)
+    elif alt == 4:
+        lib_options("wn_bwd_t", 3)          # the one-wave-per-SIMD form of the fused backward (picked beside another stream)
     g = load_golden(name)
     cfg = wn_cfg_from(g)
     m = wavenet_autoencoder(**cfg)
