@@ -36,6 +36,7 @@ struct NoCtx {};
 // store itself.  No epilogue adds atomically any more: a tile whose K range is split between workers is combined by the
 // fix-up kernel below in a fixed order (bit-reproducible), the K-major tuning mode being the one exception.
 struct EpiStore {
+  static constexpr bool PLAIN = true;
   float* C;
   long ldc;
   const float* bias;  // per column n, may be null (added by the kernel: once per column, before the row loop)
@@ -155,6 +156,21 @@ template <class Op, class = void>
 struct PerVec : std::false_type {};
 template <class Op>
 struct PerVec<Op, std::void_t<decltype(Op::PERVEC)>> : std::integral_constant<bool, Op::PERVEC> {};
+
+// An epilogue may FINISH elements: `finish4(m, n0, v, N)` receives the final sums of up to four consecutive columns of row m
+// from the fix-up kernel (the one place where a split tile's total exists) and does whatever follows the product -- the
+// LSTM backward runs the previous step's gate arithmetic there, one launch less per time step.  It is only honoured when
+// EVERY tile of the product passes through the stream-K pool (launch() tells the caller through `finished`); `active` is
+// set by launch().
+// epilogues whose output is a plain row-major matrix (C, ldc, cs, mode) take the kernel's fast store path
+template <class Epi, class = void>
+struct IsPlain : std::false_type {};
+template <class Epi>
+struct IsPlain<Epi, std::void_t<decltype(Epi::PLAIN)>> : std::integral_constant<bool, Epi::PLAIN> {};
+template <class Epi, class = void>
+struct HasFinish : std::false_type {};
+template <class Epi>
+struct HasFinish<Epi, std::void_t<decltype(&Epi::finish4)>> : std::true_type {};
 
 // ---------------------------------------------------------------- the kernel
 // bf16 operands (option "bf16", BASELINE config 5): the fp32 values are rounded to bf16 (RNE) on their way into LDS and
@@ -515,7 +531,7 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
     // and every store is one v_add on a 32-bit offset against the scalar base (global_store_dword v, v, s[C]).
     const bool atomic = kchunks > 0;       // K-major cells (tuning mode, off by default): several cells share a tile
     bool fast = false;
-    if constexpr (std::is_same<Epi, EpiStore>::value) fast = E.cs == 1 && (long)M * E.ldc < (1L << 31) && m0 + BM <= M && n0 + BN <= N;
+    if constexpr (IsPlain<Epi>::value) fast = E.cs == 1 && (long)M * E.ldc < (1L << 31) && m0 + BM <= M && n0 + BN <= N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -523,7 +539,7 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
         const int n = n0 + wn * (BN / WGN) + j * 32 + li_e;
         const float bv = (E.bias && n < N && kt0 == 0) ? E.bias[n] : 0.f;
         const int mb = m0 + wm * (BM / WGM) + i * 32;
-        if constexpr (std::is_same<Epi, EpiStore>::value) {
+        if constexpr (IsPlain<Epi>::value) {
           if (fast) {
             const unsigned ld32 = (unsigned)E.ldc;
             const unsigned base = (unsigned)(mb + 4 * lh_e) * ld32 + (unsigned)n;
@@ -591,10 +607,25 @@ __global__ void __launch_bounds__(256)
   const unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, Gu = (unsigned)G;
   const unsigned it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
   const int ga = (int)(((it0 + 1u) * Gu + R - 1u) / R) - 1, gb = (int)(((it1 + 1u) * Gu + R - 1u) / R) - 1;
-  if (gb <= ga) return;                                  // the tile was not split
-  const bool sparse = R < Gu;                            // fewer iterations than workers: some shares are empty
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e0 = strip * 256 + lane * 4;                 // tile-local element (row-major [BM][BN]) of this lane's float4
+  if (gb <= ga) {                                        // the tile was not split: its output is final already
+    if constexpr (HasFinish<Epi>::value) {
+      if (E.active && wave == 0) {
+        const unsigned tile_u = (unsigned)full_rounds * Gu + (unsigned)tr;
+        const int mu = (int)(tile_u / (unsigned)ntn) * BM + e0 / BN, nu = (int)(tile_u % (unsigned)ntn) * BN + e0 % BN;
+        if (mu < M) {
+          float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (nu + e < N) v[e] = *E.ptr(mu, nu + e);
+          E.finish4(mu, nu, v, N);
+        }
+      }
+    }
+    return;
+  }
+  const bool sparse = R < Gu;                            // fewer iterations than workers: some shares are empty
   const float* S0 = slab + e0;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   // (a worker whose share is empty wrote no slab: its slot is skipped; shares are contiguous, so every non-empty worker
@@ -621,6 +652,16 @@ __global__ void __launch_bounds__(256)
   const int m = (int)(tile / (unsigned)ntn) * BM + e0 / BN, n0 = (int)(tile % (unsigned)ntn) * BN + e0 % BN;
   if (m >= M) return;
   const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+  if constexpr (HasFinish<Epi>::value) {
+    if (E.active) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + e < N) v[e] = *E.ptr(m, n0 + e) + sv[e];
+      E.finish4(m, n0, v, N);
+      return;
+    }
+  }
 #pragma unroll
   for (int e = 0; e < 4; ++e)
     if (n0 + e < N) *E.ptr(m, n0 + e) += sv[e];
@@ -638,8 +679,9 @@ constexpr size_t SLAB_FLOATS = (size_t)512 * 128 * 128;
 // (slower on tile counts that quantise badly, still deterministic).
 // `allow_bf16`: the process-wide option "bf16" applies to this product (false for the STFT, whose DFT stays exact fp32).
 template <int BM, int BN, class AOp, class BOp, class Epi>
-static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N, int K, int split_k_hint,
-                         hipStream_t s, float* slab = nullptr, bool allow_bf16 = true) {
+static inline int launch(const AOp& a, const BOp& b, const Epi& e_in, int M, int N, int K, int split_k_hint,
+                         hipStream_t s, float* slab = nullptr, bool allow_bf16 = true, bool* finished = nullptr) {
+  Epi e = e_in;
   if (M <= 0 || N <= 0 || K <= 0) return AVVAD_EINVAL;
   const int ktiles = (K + BK - 1) / BK;
   const long ntiles = (long)cdiv(M, BM) * cdiv(N, BN);
@@ -691,6 +733,13 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
   }
   const int fr = (int)full_rounds, rt = (int)rem;
   const bool bf = allow_bf16 && tn.bf16;
+  if constexpr (HasFinish<Epi>::value) {
+    // finish4() runs in the fix-up kernel: only when every tile of the product goes through the stream-K pool
+    e.active = (rt > 0 && kchunks == 0 && fr == 0 && (long)rt == ntiles) ? 1 : 0;
+    if (finished) *finished = e.active != 0;
+  } else if (finished) {
+    *finished = false;
+  }
 #define AVVAD_IGEMM_LAUNCH(DBV, NTHV)                                                                                       \
   do {                                                                                                                      \
     if (bf)                                                                                                                 \

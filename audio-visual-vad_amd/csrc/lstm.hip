@@ -353,6 +353,52 @@ __global__ void lstm_gates_bwd(float* __restrict__ G, const float* __restrict__ 
   DC[idx] = dc * fg;
 }
 
+// Epilogue of the backward recurrent product DH = dG_t . W_hh (rows = sequences, columns = hidden units): the engine's
+// fix-up kernel, which is where a split tile's total exists, hands each finished dh to finish4(), and that runs the gate
+// backward of step t - 1 on the spot (lstm_gates_bwd's arithmetic) -- two launches per time step instead of three.
+struct EpiLstmBwd {
+  static constexpr bool PLAIN = true;
+  float* C;            // DH [B][H]
+  long ldc;
+  const float* bias;   // null
+  int mode;            // 0: the first piece of a tile overwrites DH
+  int cs;
+  int active;          // set by igemm::launch(): every tile goes through the fix-up
+  float* G;
+  const float* Cs;
+  const float* dy;
+  float* DC;
+  const int* lengths;
+  int T, H, t;         // t: the step whose gates are differentiated (the product's step minus one)
+  __device__ __forceinline__ float* ptr(int m, int n) const { return C + (long)m * ldc + n; }
+  __device__ __forceinline__ void finish4(int b, int j0, const float (&dhr)[4], int N) const {
+    const bool live = t < lengths[b];
+    float* g = G + ((long)b * T + t) * 4 * H;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      if (j >= N) continue;
+      const int idx = b * H + j;
+      const long o = ((long)b * T + t) * H + j;
+      if (!live) {
+        g[j] = 0.f; g[H + j] = 0.f; g[2 * H + j] = 0.f; g[3 * H + j] = 0.f;
+        DC[idx] = 0.f;
+        continue;
+      }
+      const float ig = g[j], fg = g[H + j], gg = g[2 * H + j], og = g[3 * H + j];
+      const float c = Cs[o], cp = t > 0 ? Cs[o - H] : 0.f;
+      const float tc = tanhf(c);
+      const float dh = dy[o] + dhr[e];
+      const float dc = DC[idx] + dh * og * (1.f - tc * tc);
+      g[j] = dc * gg * ig * (1.f - ig);
+      g[H + j] = dc * cp * fg * (1.f - fg);
+      g[2 * H + j] = dc * ig * (1.f - gg * gg);
+      g[3 * H + j] = dh * tc * og * (1.f - og);
+      DC[idx] = dc * fg;
+    }
+  }
+};
+
 __global__ void shift_time(const float* __restrict__ y, float* __restrict__ ys, int B, int T, int H) {
   const long n = (long)B * T * H;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -504,12 +550,24 @@ extern "C" int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const flo
   hipLaunchKernelGGL(fill0, dim3(grid1(B * H)), dim3(256), 0, s, w.DH, (long)B * H);
   hipLaunchKernelGGL(fill0, dim3(grid1(B * H)), dim3(256), 0, s, w.DC, (long)B * H);
   const int split = pick_split(B, H, 4 * H);
+  // fused form: the product's fix-up finishes step t - 1's gates (EpiLstmBwd); needs the 64x64 tile path with 16-byte rows
+  const bool fuse = (B <= 64 || H <= 64) && H % 4 == 0 && ((uintptr_t)w_hh % 16 == 0) && !avvad_tune().lstm_no_fused_step;
+  bool gates_done = false;     // step t's gate backward already ran inside the previous product's fix-up
   for (int t = T - 1; t >= 0; --t) {
-    hipLaunchKernelGGL(lstm_gates_bwd, dim3(cdiv(B * H, 256)), dim3(256), 0, s, w.G, w.Cs, dy, w.DH, w.DC, d->lengths, B, T,
-                       H, t);
+    if (!gates_done)
+      hipLaunchKernelGGL(lstm_gates_bwd, dim3(cdiv(B * H, 256)), dim3(256), 0, s, w.G, w.Cs, dy, w.DH, w.DC, d->lengths, B, T,
+                         H, t);
+    gates_done = false;
     if (t > 0) {  // DH = dG_t . W_hh   ([B][4H] x [4H][H])
-      avvad_gemm_desc rd = gemm_desc(B, H, 4 * H, T * 4 * H, H, H, 0, 0, 1, split);
-      if ((rc = avvad_gemm_impl(w.G + (long)t * 4 * H, w_hh, nullptr, w.DH, &rd, s, w.slab))) return rc;
+      if (fuse) {
+        igemm::RowPlain a{w.G + (long)t * 4 * H, (long)T * 4 * H, B, 4 * H, 0};
+        igemm::ColPlain<4> bop{w_hh, H, H, 4 * H, 0};
+        EpiLstmBwd e{w.DH, H, nullptr, 0, 1, 0, w.G, w.Cs, dy, w.DC, d->lengths, T, H, t - 1};
+        if ((rc = igemm::launch<64, 64>(a, bop, e, B, H, 4 * H, split, s, w.slab, true, &gates_done))) return rc;
+      } else {
+        avvad_gemm_desc rd = gemm_desc(B, H, 4 * H, T * 4 * H, H, H, 0, 0, 1, split);
+        if ((rc = avvad_gemm_impl(w.G + (long)t * 4 * H, w_hh, nullptr, w.DH, &rd, s, w.slab))) return rc;
+      }
     }
   }
   const int R = B * T;
