@@ -40,6 +40,10 @@ int avvad_gemm_impl(const float* A, const float* B, const float* bias, float* C,
   igemm::EpiStore e{C, d->ldc, bias, d->split_k > 1 ? 2 : (d->accumulate ? 1 : 0)};
   if (bias && d->split_k > 1) return AVVAD_EINVAL;
   if (!d->transA) {  // [M][K]
+    if (d->lda % 4 == 0 && d->K % 4 == 0 && (uintptr_t)A % 16 == 0 && (long)d->M * d->lda < (1L << 29) - 64) {
+      igemm::RowVec4 a{A, d->lda, d->M, d->K, d->relu_a};     // 16-byte buffer fetches along K
+      return runA(a, B, e, d, s, slab);
+    }
     igemm::RowPlain a{A, d->lda, d->M, d->K, d->relu_a};
     return runA(a, B, e, d, s, slab);
   }

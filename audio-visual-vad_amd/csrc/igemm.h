@@ -64,6 +64,26 @@ struct RowPlain {
   __device__ __forceinline__ float post(float v) const { return relu ? fmaxf(v, 0.f) : v; }
 };
 
+// element (x, k) = p[x*ld + k], four consecutive k per 16-byte buffer fetch (K % 4 == 0, ld % 4 == 0, 16-byte aligned base,
+// operand < 2 GiB: checked by the caller).  The scalar RowPlain above issues 8 guarded one-dword loads per thread and K tile
+// for a 64-row tile; this one issues 2 and needs no validity select (out-of-range rows carry BUF_OOB and read as 0).
+struct RowVec4 {
+  static constexpr bool KCONTIG = true;
+  static constexpr int VEC = 4;
+  typedef NoCtx Ctx;
+  const float* p;
+  long ld;
+  int X, K, relu;
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
+  __device__ __forceinline__ void load(const Ctx&, int x, int k0, int kin, float* v) const {
+    const int k = k0 + kin;
+    const bool ok = x < X && k < K;
+    const f4v t = bload4(brsrc2g(p), ok ? (int)(((unsigned)x * (unsigned)ld + (unsigned)k) * 4u) : BUF_OOB, 0);
+    v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+  }
+  __device__ __forceinline__ float post(float v) const { return relu ? fmaxf(v, 0.f) : v; }
+};
+
 // element (x, k) = p[b*bstride + x*ld + t + shift], k = b*seglen + t   (batch-segmented K:
 // the Conv1d weight gradients contract over (sequence, time))
 struct RowSegK {

@@ -551,7 +551,8 @@ extern "C" int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const flo
   hipLaunchKernelGGL(fill0, dim3(grid1(B * H)), dim3(256), 0, s, w.DC, (long)B * H);
   const int split = pick_split(B, H, 4 * H);
   // fused form: the product's fix-up finishes step t - 1's gates (EpiLstmBwd); needs the 64x64 tile path with 16-byte rows
-  const bool fuse = (B <= 64 || H <= 64) && H % 4 == 0 && ((uintptr_t)w_hh % 16 == 0) && !avvad_tune().lstm_no_fused_step;
+  const bool fuse = (B <= 64 || H <= 64) && H % 4 == 0 && ((uintptr_t)w_hh % 16 == 0) && !avvad_tune().lstm_no_fused_step &&
+                    (long)B * T * 4 * H < (1L << 29) - 64;
   bool gates_done = false;     // step t's gate backward already ran inside the previous product's fix-up
   for (int t = T - 1; t >= 0; --t) {
     if (!gates_done)
@@ -560,7 +561,7 @@ extern "C" int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const flo
     gates_done = false;
     if (t > 0) {  // DH = dG_t . W_hh   ([B][4H] x [4H][H])
       if (fuse) {
-        igemm::RowPlain a{w.G + (long)t * 4 * H, (long)T * 4 * H, B, 4 * H, 0};
+        igemm::RowVec4 a{w.G + (long)t * 4 * H, (long)T * 4 * H, B, 4 * H, 0};     // (4H % 4 == 0, rows 16-byte aligned)
         igemm::ColPlain<4> bop{w_hh, H, H, 4 * H, 0};
         EpiLstmBwd e{w.DH, H, nullptr, 0, 1, 0, w.G, w.Cs, dy, w.DC, d->lengths, T, H, t - 1};
         if ((rc = igemm::launch<64, 64>(a, bop, e, B, H, 4 * H, split, s, w.slab, true, &gates_done))) return rc;
