@@ -155,6 +155,8 @@ __global__ void __launch_bounds__(1024)
 // step barrier is one agent-scope atomic add per workgroup (behind s_waitcnt vmcnt(0) of every storing wave and a workgroup
 // barrier) polled by one lane with sc1 loads: MI355X_MICROARCH "Valid forms", first table row.  No agent-scope fences: the
 // release/acquire fences of round 1's persistent attempt wrote back and invalidated whole L2s every step and lost 0.4 ms.
+// (Tried: 8 waves per workgroup, each a K eighth, held to 128 registers so that two workgroups still fit a CU: 18 spills and
+//  the stack forward went from 0.68 to 0.73 ms.)
 // Every spin is BOUNDED: if the grid ever failed to be co-resident the launch ends (status word set, results wrong and
 // loudly so) instead of hanging the device.
 template <int NK>   // H / 64: float4 fragments per lane and K quarter
