@@ -36,6 +36,7 @@ struct AvvadTune {
   int no_tall;              // 128x64 tiles instead of 256x64 for the 64-channel convolutions
   int wn_no_fused_tail;     // unfused encoder tail backward
   int wn_no_fused_wgrad;    // unfused encoder block backward (dz, weight gradients as separate kernels)
+  int no_fixup1;             // tuning aid: always the four-wave fix-up kernel
   int no_buf;                // convolution gathers with flat addressing + validity selects (the form operands >= 2 GiB use)
   int wn_flat;               // residual-block forward: 0 by size, 1 flat dword kernel, 2 dword buffer kernel, 3 wide (dwordx4) buffer kernel
   int wn_dx;                 // dx kernel: 0 by the descriptor's shared_device hint, 1 resident weights + cross-tile prefetch, 2 high occupancy

@@ -687,6 +687,64 @@ __global__ void __launch_bounds__(256)
     if (n0 + e < N) *E.ptr(m, n0 + e) += sv[e];
 }
 
+// The same fix-up for SHALLOW splits (a tile cut between a handful of workers: the convolutions' stream-K rounds): one WAVE
+// per strip, four strips per workgroup, the wave walks its tile's slabs itself.  The kernel above spends four waves, an LDS
+// exchange and a barrier on every strip; with ~3 slabs per tile three of them load one slab each -- a 136-tile round was
+// 34816 waves for 43 MB, 15 us.  (Deep splits -- the LSTM's 31-way, the weight gradients' 100-way tiles -- keep the
+// four-wave form.)
+template <int BM, int BN, class Epi>
+__global__ void __launch_bounds__(256)
+    fixup1(const Epi E, const float* __restrict__ slab, const int M, const int N, const int ktiles, const long G,
+           const int full_rounds, const int rem_tiles, const int ntn) {
+  constexpr int STRIPS = BM * BN / 256;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sg = blockIdx.x * 4 + wave;
+  const int tr = sg / STRIPS, strip = sg % STRIPS;
+  if (tr >= rem_tiles) return;
+  const unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, Gu = (unsigned)G;
+  const unsigned it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  const int ga = (int)(((it0 + 1u) * Gu + R - 1u) / R) - 1, gb = (int)(((it1 + 1u) * Gu + R - 1u) / R) - 1;
+  const int e0 = strip * 256 + lane * 4;
+  const unsigned tile = (unsigned)full_rounds * Gu + (unsigned)tr;
+  const int m = (int)(tile / (unsigned)ntn) * BM + e0 / BN, n0 = (int)(tile % (unsigned)ntn) * BN + e0 % BN;
+  if (m >= M) return;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (gb > ga) {
+    const bool sparse = R < Gu;
+    const float* S0 = slab + e0;
+    for (int g = ga + 1; g <= gb; g += 4) {
+      float4 v[4];
+      bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int gu = g + u;
+        ok[u] = gu <= gb && (!sparse || ((unsigned)(gu + 1) * R) / Gu > ((unsigned)gu * R) / Gu);
+        v[u] = *reinterpret_cast<const float4*>(S0 + (long)(ok[u] ? gu : ga + 1) * (BM * BN));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (ok[u]) { sum.x += v[u].x; sum.y += v[u].y; sum.z += v[u].z; sum.w += v[u].w; }
+    }
+  } else if (!HasFinish<Epi>::value) {
+    return;                                              // unsplit tile, nothing to finish
+  }
+  const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
+  if constexpr (HasFinish<Epi>::value) {
+    if (E.active) {
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (n0 + e < N) v[e] = *E.ptr(m, n0 + e) + sv[e];
+      E.finish4(m, n0, v, N);
+      return;
+    }
+    if (gb <= ga) return;
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (n0 + e < N) *E.ptr(m, n0 + e) += sv[e];
+}
+
 constexpr int NUM_CU = 256;  // MI355X
 
 // Floats of slab workspace a launch may need: one BM x BN tile per persistent worker (512 x 128x128 = 1024 x 128x64 =
@@ -777,8 +835,13 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e_in, int M, int
     else AVVAD_IGEMM_LAUNCH(true, (BIG ? 512 : 256));
   }
 #undef AVVAD_IGEMM_LAUNCH
-  if (rt > 0 && kchunks == 0)
-    hipLaunchKernelGGL((fixup<BM, BN, Epi>), dim3(rt * (BM * BN / 256)), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));
+  if (rt > 0 && kchunks == 0) {
+    const int deep = tn.no_fixup1 > 1 ? tn.no_fixup1 : 6;     // (option values > 1: the depth threshold, tuning aid)
+    if ((G + rt - 1) / rt <= deep && tn.no_fixup1 != 1)      // a handful of slabs per tile: one wave per strip
+      hipLaunchKernelGGL((fixup1<BM, BN, Epi>), dim3(rt * (BM * BN / 1024)), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));
+    else
+      hipLaunchKernelGGL((fixup<BM, BN, Epi>), dim3(rt * (BM * BN / 256)), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));
+  }
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

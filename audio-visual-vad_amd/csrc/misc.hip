@@ -22,6 +22,7 @@ const OptName kOpts[] = {
     {"wn_no_fused_wgrad", "AVVAD_WN_NO_FUSED_WGRAD", &AvvadTune::wn_no_fused_wgrad},
     {"wn_bwd_t", "AVVAD_WN_BWD_T", &AvvadTune::wn_bwd_t},
     {"no_buf", "AVVAD_NO_BUF", &AvvadTune::no_buf},
+    {"no_fixup1", "AVVAD_NO_FIXUP1", &AvvadTune::no_fixup1},
     {"wn_flat", "AVVAD_WN_FLAT", &AvvadTune::wn_flat},
     {"wn_grid", "AVVAD_WN_GRID", &AvvadTune::wn_grid},
     {"wn_dx", "AVVAD_WN_DX", &AvvadTune::wn_dx},
@@ -31,7 +32,7 @@ const OptName kOpts[] = {
 int parse_opt(const char* name, const char* v) {
   if (!strcmp(name, "igemm_variant")) return v[0] == 'd' ? 0 : (v[0] == 's' ? 1 : (v[0] == 'w' ? 2 : atoi(v)));
   if (!strcmp(name, "no_streamk")) return v[0] == 'a' ? 1 : (v[0] >= '0' && v[0] <= '9' && !v[1] ? 10 + (v[0] - '0') : atoi(v));
-  if (!strcmp(name, "max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid") || !strcmp(name, "wn_dx") || !strcmp(name, "wn_bwd_t")) return atoi(v);
+  if (!strcmp(name, "max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid") || !strcmp(name, "wn_dx") || !strcmp(name, "wn_bwd_t") || !strcmp(name, "no_fixup1")) return atoi(v);
   return (v[0] && strcmp(v, "0")) ? 1 : 0;
 }
 }  // namespace

@@ -43,7 +43,7 @@ int avvad_abi_version(void);
 
 /* Schedule options (tuning / debugging; production leaves them alone).  Names:
  *   "no_streamk" (1 = whole-tile GEMM schedule), "igemm_variant", "kmajor", "no_tall", "no_stem_kernel",
- *   "no_buf" (1 = convolution gathers with flat addressing + validity selects, the form operands >= 2 GiB use),
+ *   "no_fixup1" (1 = always the four-wave fix-up kernel), "no_buf" (1 = convolution gathers with flat addressing + validity selects, the form operands >= 2 GiB use),
  *   "lstm_no_fused_step", "lstm_no_persistent", "wn_no_fused_tail", "wn_no_fused_wgrad", "wn_bwd_t",
  *   "wn_flat" (encoder block forward: 0 by plane length, 1 flat dword kernel, 2 buffer dword kernel with resident
  *   weights, 3 dwordx4 kernel, 4 high-occupancy kernel), "wn_dx" / "wn_bwd_t" (0 by the descriptor's shared_device hint, other values force
