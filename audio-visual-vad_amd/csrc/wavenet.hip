@@ -899,6 +899,7 @@ __global__ void __launch_bounds__(256)
   // buffer addressing (common.h): one wave per SIMD is resident, so every VALU instruction adds to the MFMA time; the flat
   // form spent ~1150 of them per tile on the 64-bit addresses of the 384 pooled-gradient gathers alone
   const int rowV = Lv * 4;
+  const bool single = (Lv % P) == 0;
   for (long tile = wave0; tile < ntiles; tile += nwaves) {
     const int b = __builtin_amdgcn_readfirstlane((int)(tile / tiles_per_seq));
     const int t = (int)(tile - (long)b * tiles_per_seq) * 32 + li;
@@ -959,8 +960,12 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         float g = 0.f;
+        if (single) {          // Lv % P == 0: the bins do not overlap, candidate 1 (bin t*P/Lv) is the only member
+          g = bload(rg, pbo[1], (nb + mfma32_row(r, 0)) * P * 4) * pc[1];
+        } else {
 #pragma unroll
-        for (int j = 0; j < 3; ++j) g = fmaf(bload(rg, pbo[j], (nb + mfma32_row(r, 0)) * P * 4), pc[j], g);   // pb clamped to a valid bin, pc = 0 when not a member
+          for (int j = 0; j < 3; ++j) g = fmaf(bload(rg, pbo[j], (nb + mfma32_row(r, 0)) * P * 4), pc[j], g);   // pb clamped to a valid bin, pc = 0 when not a member
+        }
         dz[r] = accZ[r] > 0.f ? g : 0.f;                                   // (0 outside the sequence: pc = 0)
       }
 #pragma unroll
