@@ -128,7 +128,10 @@ __global__ void pack_weights(const float* __restrict__ w, float* __restrict__ wf
   }
 }
 // all 20 convolutions' weights in ONE launch (19 separate launches of ~9 us each were 0.17 ms of a 22 ms step): the block
-// index selects the convolution through a small table of block ranges
+// index selects the convolution through a small table of block ranges.  A workgroup owns a 32 (co) x 32 (c) tile of one
+// convolution: its OIHW source is 32 contiguous runs of 32*T floats, read coalesced into LDS; each of the T taps then
+// leaves as a 32x32 tile whose rows are contiguous in the packed layouts (co for the forward pack, c for the dgrad pack).
+// (One thread per element wrote 4-byte scatters a whole channel plane apart: 92 us for 135 MB.)
 struct PackTab {
   const float* w[NCONV];
   float* wf[NCONV];
@@ -136,28 +139,37 @@ struct PackTab {
   int cout[NCONV], cin[NCONV], ks[NCONV];
   int blk0[NCONV + 1];   // first block of conv i (conv 0 = stem: its 3 input channels are folded, see pack_stem)
 };
+constexpr int PACK_LD = 32 * 9 + 1;
 __global__ void __launch_bounds__(256) pack_all(const PackTab tab) {
+  __shared__ float tl[32 * PACK_LD];
   int i = 0;
 #pragma unroll
   for (int j = 1; j < NCONV; ++j) i += (int)blockIdx.x >= tab.blk0[j];      // block-uniform
-  const int e = ((int)blockIdx.x - tab.blk0[i]) * 256 + threadIdx.x;
+  const int lb = (int)blockIdx.x - tab.blk0[i];
   const float* w = tab.w[i];
   float* wf = tab.wf[i];
   if (i == 0) {
+    const int e = lb * 256 + threadIdx.x;
     if (e >= 64 * 49) return;
     const int co = e / 49, k = e % 49;
     wf[k * 64 + co] = w[(co * 3 + 0) * 49 + k] + w[(co * 3 + 1) * 49 + k] + w[(co * 3 + 2) * 49 + k];
     return;
   }
-  const int Co = tab.cout[i], C = tab.cin[i], KS = tab.ks[i];
-  if (e >= Co * C * KS * KS) return;
-  int r = e;
-  const int kw = r % KS; r /= KS;
-  const int kh = r % KS; r /= KS;
-  const int c = r % C; const int co = r / C;
-  const float v = w[e];
-  wf[((long)(kh * KS + kw) * C + c) * Co + co] = v;
-  if (tab.wd[i]) tab.wd[i][((long)(kh * KS + kw) * Co + co) * C + c] = v;
+  const int Co = tab.cout[i], C = tab.cin[i], T = tab.ks[i] * tab.ks[i];     // T = 9 or 1; Co, C multiples of 32
+  const int ctiles = C >> 5;
+  const int co0 = (lb / ctiles) * 32, c0 = (lb % ctiles) * 32;
+  const int run = 32 * T;
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int col = idx / run, r = idx - col * run;
+    tl[col * PACK_LD + r] = w[((long)(co0 + col) * C + c0) * T + r];
+  }
+  __syncthreads();
+  float* wd = tab.wd[i];
+  for (int idx = threadIdx.x; idx < T * 1024; idx += 256) {
+    const int tap = idx >> 10, a = (idx >> 5) & 31, b = idx & 31;
+    wf[((long)(tap * C + c0 + a)) * Co + co0 + b] = tl[b * PACK_LD + a * T + tap];           // row (tap, c = a), column co = b
+    if (wd) wd[((long)(tap * Co + co0 + a)) * C + c0 + b] = tl[a * PACK_LD + b * T + tap];    // row (tap, co = a), column c = b
+  }
 }
 // stem: fold the 3 identical input channels (Video_Net.py:64): Wf[kh*7+kw][co] = sum_c w[co][c][kh][kw]
 __global__ void pack_stem(const float* __restrict__ w, float* __restrict__ wf) {
@@ -175,25 +187,34 @@ struct UnpackTab {
   int blk0[NCONV + 1];
 };
 __global__ void __launch_bounds__(256) unpack_all(const UnpackTab tab) {
+  __shared__ float tl[32 * PACK_LD];
   int i = 0;
 #pragma unroll
   for (int j = 1; j < NCONV; ++j) i += (int)blockIdx.x >= tab.blk0[j];      // block-uniform
-  const int e = ((int)blockIdx.x - tab.blk0[i]) * 256 + threadIdx.x;
+  const int lb = (int)blockIdx.x - tab.blk0[i];
   float* dw = tab.dw[i];
   if (!dw) return;
   const float* pk = tab.pk[i];
   if (i == 0) {
+    const int e = lb * 256 + threadIdx.x;
     if (e >= 64 * 3 * 49) return;
     dw[e] += pk[(e % 49) * 64 + e / 147];
     return;
   }
-  const int Co = tab.cout[i], C = tab.cin[i], KS = tab.ks[i];
-  if (e >= Co * C * KS * KS) return;
-  int r = e;
-  const int kw = r % KS; r /= KS;
-  const int kh = r % KS; r /= KS;
-  const int c = r % C; const int co = r / C;
-  dw[e] += pk[((long)(kh * KS + kw) * C + c) * Co + co];
+  // the mirror image of pack_all: a 32 (co) x 32 (c) tile, T taps read as rows of co, added onto 32 contiguous OIHW runs
+  const int Co = tab.cout[i], C = tab.cin[i], T = tab.ks[i] * tab.ks[i];
+  const int ctiles = C >> 5;
+  const int co0 = (lb / ctiles) * 32, c0 = (lb % ctiles) * 32;
+  for (int idx = threadIdx.x; idx < T * 1024; idx += 256) {
+    const int tap = idx >> 10, a = (idx >> 5) & 31, b = idx & 31;
+    tl[b * PACK_LD + a * T + tap] = pk[((long)(tap * C + c0 + a)) * Co + co0 + b];
+  }
+  __syncthreads();
+  const int run = 32 * T;
+  for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+    const int col = idx / run, r = idx - col * run;
+    dw[((long)(co0 + col) * C + c0) * T + r] += tl[col * PACK_LD + r];
+  }
 }
 
 // ------------------------------------------------------------------ stem convolution 7x7 / 2, 1 -> 64 channels (frames that fit LDS)
@@ -623,7 +644,7 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
       tab.wd[i] = (i > 0 && d->save_for_backward) ? ws + p.wd[i] : (float*)nullptr;
       tab.cout[i] = c.cout; tab.cin[i] = c.cin; tab.ks[i] = c.ks;
       tab.blk0[i] = nb;
-      nb += cdiv(i == 0 ? 64 * 49 : (long)c.cout * c.cin * c.ks * c.ks, 256);
+      nb += i == 0 ? cdiv(64 * 49, 256) : (c.cout / 32) * (c.cin / 32);
     }
     tab.blk0[NCONV] = nb;
     hipLaunchKernelGGL(pack_all, dim3(nb), dim3(256), 0, s, tab);
@@ -750,7 +771,7 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
       tab.dw[i] = done ? g->conv_w[i] : (float*)nullptr;
       tab.cout[i] = c.cout; tab.cin[i] = c.cin; tab.ks[i] = c.ks;
       tab.blk0[i] = nb;
-      nb += cdiv(i == 0 ? 64 * 3 * 49 : (long)c.cout * c.cin * c.ks * c.ks, 256);
+      nb += i == 0 ? cdiv(64 * 3 * 49, 256) : (c.cout / 32) * (c.cin / 32);
       any = any || done;
     }
     tab.blk0[NCONV] = nb;
