@@ -372,6 +372,95 @@ __global__ void zero_f32(float* p, long n) {
 
 static inline int ew_grid(long n) { long b = (n + 255) / 256; return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b)); }
 
+// ------------------------------------------------------------------ stem weight gradient 7x7 / 2, 1 -> 64 channels
+//   pk[k = kh*7 + kw][co] = sum_{n, ho, wo} x[n][2 ho - 3 + kh][2 wo - 3 + kw] * dy[n][ho][wo][co]
+// On the engine this 49 x 64 x (N*Ho*Wo) product ran on scalar gathers (198 us, 37 TFLOP/s).  Here a workgroup walks whole
+// frames: the zero-padded frame sits in LDS (as in stem_fwd_mfma), the contraction index is the output pixel -- lane half h
+// takes pixel (ho, 2 s + h) -- so the A operand of tap (kh, kw) is the LDS word  kh*LDW + kw + 2h  +  (2 ho LDW + 4 s):
+// a per-lane constant plus a wave-uniform offset, conflict-free (LDW odd), and the B operand dy[pixel][co] is a coalesced
+// row.  Wave (mt, nt) owns taps 32 mt .. 32 mt + 31 (49 live) x channels 32 nt .. 32 nt + 31 in one accumulator for all its
+// frames; per-workgroup sums leave through slabs and are added in workgroup order (deterministic).
+constexpr int STEM_WH = 17;      // Wo / 2 of the production geometry (34 output columns); the kernel takes Wo <= 34, even
+__global__ void __launch_bounds__(256)
+    stem_wgrad_mfma(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ slab, int N, int H, int W,
+                    int Ho, int Wo, int LDW) {
+  extern __shared__ float img[];                     // (H + 6) x LDW, zero border of 3
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int mt = wave >> 1, nt = wave & 1;
+  const int tap = mt * 32 + li;
+  const int tc = tap < 49 ? tap : 0;                 // rows >= 49 of the accumulator are never stored
+  const int abase = (tc / 7) * LDW + (tc % 7) + 2 * lh;
+  const int PH = H + 6, wh = Wo >> 1;
+  for (int i = threadIdx.x; i < PH * LDW; i += 256) img[i] = 0.f;      // the border stays zero for every frame
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int voff = (lh * 64 + nt * 32 + li) * 4;
+  for (int n = blockIdx.x; n < N; n += gridDim.x) {
+    __syncthreads();                                 // the previous frame's reads are done
+    const float* xn = x + (long)n * H * W;
+    for (int i = threadIdx.x; i < H * W; i += 256) {
+      const int r = i / W, c = i - r * W;
+      img[(r + 3) * LDW + c + 3] = xn[i];
+    }
+    __syncthreads();
+    const __amdgpu_buffer_rsrc_t rdy = brsrc(dy + (long)n * Ho * Wo * 64, Ho * Wo * 64 * 4);
+    // dy rows in batches of RB: the NEXT batch (RB x 17 loads) is in flight under this batch's RB x 17 MFMAs (~1.8 us: one
+    // row ahead, 0.45 us, was shorter than the memory latency and the kernel ran 150 us instead of the engine's 198)
+    constexpr int RB = 4;
+    float b0[RB][STEM_WH], b1[RB][STEM_WH];
+    auto rowload = [&](int ho0, float (&b)[RB][STEM_WH]) {
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr)
+#pragma unroll
+        for (int sw = 0; sw < STEM_WH; ++sw)
+          b[rr][sw] = bload(rdy, (sw < wh && ho0 + rr < Ho) ? voff : BUF_OOB, ((ho0 + rr) * Wo + 2 * sw) * 256);
+    };
+    auto rowmul = [&](int ho0, const float (&b)[RB][STEM_WH]) {
+#pragma unroll
+      for (int rr = 0; rr < RB; ++rr) {
+        if (ho0 + rr >= Ho) break;
+        const float* ap = img + abase + 2 * (ho0 + rr) * LDW;
+#pragma unroll
+        for (int sw = 0; sw < STEM_WH; ++sw)
+          if (sw < wh) acc = mfma32(ap[4 * sw], b[rr][sw], acc);
+      }
+    };
+    rowload(0, b0);
+    for (int ho = 0; ho < Ho; ho += 2 * RB) {
+      if (ho + RB < Ho) rowload(ho + RB, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      rowmul(ho, b0);
+      if (ho + RB >= Ho) break;
+      if (ho + 2 * RB < Ho) rowload(ho + 2 * RB, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      rowmul(ho + RB, b1);
+    }
+  }
+  float* out = slab + (long)blockIdx.x * (49 * 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = mt * 32 + mfma32_row(r, lh);
+    if (t < 49) out[t * 64 + nt * 32 + li] = acc[r];
+  }
+}
+// pk[k][co] = sum over workgroups of slab[.][k][co], ascending: 32 elements x 8 slab groups per workgroup, combined in order
+__global__ void __launch_bounds__(256) stem_wgrad_reduce(const float* __restrict__ slab, int nslab, float* __restrict__ pk) {
+  __shared__ float sm[8][32];
+  const int el = threadIdx.x & 31, grp = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + el;                // 49 * 64 = 98 * 32
+  float s = 0.f;
+#pragma unroll 4
+  for (int b = grp; b < nslab; b += 8) s += slab[(long)b * (49 * 64) + i];
+  sm[grp][el] = s;
+  __syncthreads();
+  if (grp != 0) return;
+#pragma unroll
+  for (int k = 1; k < 8; ++k) s += sm[k][el];
+  pk[i] = s;
+}
+
 // ------------------------------------------------------------------ conv launchers
 static inline bool fits_u31(long n) { return n >= 0 && n < (1L << 31); }
 // operands below 2 GiB take the buffer-addressed gathers (conv_ops.h "BUF")
@@ -458,6 +547,16 @@ static int conv_wgrad_t(const float* x, const float* dy, float* pk, const Geom& 
   igemm::ColPlain<4, BUF> b{dy, g.Co, g.Co, K, 0};
   const int ktiles = cdiv(K, igemm::BK);
   if (g.C == 1) {
+    const int LDW = (g.W + 6) | 1;
+    const size_t lds = (size_t)(g.H + 6) * LDW * sizeof(float);
+    if (g.KS == 7 && g.stride == 2 && g.pad == 3 && g.Co == 64 && (g.Wo & 1) == 0 && g.Wo <= 2 * STEM_WH && lds <= 48 * 1024 &&
+        slab && !avvad_tune().no_stem_kernel && (long)g.Ho * g.Wo * 64 * 4 < (1L << 31)) {
+      const int nb = g.N < 256 ? g.N : 256;                       // one workgroup per CU, whole frames each
+      hipLaunchKernelGGL(stem_wgrad_mfma, dim3(nb), dim3(256), lds, s, x, dy, slab, g.N, g.H, g.W, g.Ho, g.Wo, LDW);
+      hipLaunchKernelGGL(stem_wgrad_reduce, dim3(49 * 64 / 32), dim3(256), 0, s, slab, nb, pk);
+      AVVAD_LAUNCH_CHECK();
+      return AVVAD_OK;
+    }
     igemm::EpiStore e{pk, g.Co, nullptr, 0};
     convop::StemWgradX a{x, g, M, K};
     int split = 1024; if (split > ktiles) split = ktiles;
