@@ -10,12 +10,16 @@
 // residual block: one wave owns a 32-sample time tile; lane half h of the wave
 // streams tap h (x[c][t + h*d]) straight from HBM into the B operand of
 // v_mfma_f32_32x32x2_f32 -- the dilation gather is the lane-half assignment,
-// no LDS, no shuffles -- all 3072 block weights sit in registers as A
-// operands, and the first GEMM's accumulator tile (rows = dilation channels in
-// registers, column = time on the lane) is consumed in place as the B operand
-// of the 1x1 "dense" GEMM (k-order permuted to the accumulator's row order).
-// ReLUs, both biases and the left-cropped residual are fused; each activation
-// is read once (+ once for the residual, an L2 hit) and written once.
+// no LDS, no shuffles -- and the first GEMM's accumulator tile (rows = dilation
+// channels in registers, column = time on the lane) is consumed in place as the
+// B operand of the 1x1 "dense" GEMM (k-order permuted to the accumulator's row
+// order).  ReLUs, both biases and the left-cropped residual are fused; each
+// activation is read once (+ once for the residual, an L2 hit) and written once.
+// The block kernels come in several forms of the same arithmetic (options wn_flat,
+// wn_dx, wn_bwd_t): buffer-addressed with the weights read
+// from LDS and 4 waves per SIMD (the default for short planes), 16-byte memory
+// instructions over 128-sample super-tiles (long planes), resident weights with a
+// cross-tile prefetch (beside another stream's kernels), flat addressing (round 1).
 // Any other (R, D, filter_width) runs generic direct kernels.
 // Weight gradients contract over (sequence, time) on the igemm engine.
 #include "gemm_api.h"
