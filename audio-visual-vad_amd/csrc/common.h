@@ -39,7 +39,7 @@ struct AvvadTune {
   int no_fixup1;             // tuning aid: always the four-wave fix-up kernel
   int no_buf;                // convolution gathers with flat addressing + validity selects (the form operands >= 2 GiB use)
   int wn_flat;               // residual-block forward: 0 by size, 1 flat dword kernel, 2 dword buffer kernel, 3 wide (dwordx4) buffer kernel
-  int wn_dx;                 // dx kernel: 0 by the descriptor's shared_device hint, 1 resident weights + cross-tile prefetch, 2 high occupancy
+  int wn_dx;                 // dx kernel: 0 by the descriptor's shared_device hint, 1 resident weights + cross-tile prefetch, 2 high occupancy, 3 round 1's flat kernel
   int wn_grid;               // tuning aid: workgroup cap of the wide residual-block kernels (0 = default)
   int wn_bwd_t;             // fused block backward: 0 by the descriptor's shared_device hint, 1 transposed products, 2 high occupancy, 3 resident weights
   int bf16;                 // bf16-input MFMA (fp32 accumulate) for the convolutions and dense GEMMs: BASELINE config 5's arithmetic

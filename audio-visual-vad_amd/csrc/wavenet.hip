@@ -680,6 +680,70 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+// BUFFER-ADDRESSED form of (B) with the weights resident and the next tile's requests in flight under this tile's MFMAs:
+// the low-occupancy form picked beside another stream's kernels (descriptor hint shared_device), where the flat kernel
+// above ran until now -- 720 VALU instructions per 32 MFMAs, most of them 64-bit address arithmetic and validity selects.
+__global__ void __launch_bounds__(256)
+    wn_block_bwd_dx_buf(const float* __restrict__ DZ, const float* __restrict__ s_in, const float* __restrict__ dS_out,
+                        const float* __restrict__ w_dil, float* __restrict__ dS_in, int B, int Lin, int dil) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lin + 31) >> 5;
+  const int ntiles = B * tiles_per_seq;
+  __shared__ float wl[32 * 65];
+  const int rowL = Lin * 4, rowO = Lo * 4;
+  // request tile `tile` (clamped to the last tile when there is none: the values are then never used)
+  auto issue = [&](int tile, float (&dzn)[32], float (&svn)[16], float (&rvn)[16]) {
+    const int tc = tile < ntiles ? tile : ntiles - 1;
+    const int b = tc / tiles_per_seq;
+    const int t = (tc - b * tiles_per_seq) * 32 + li;
+    const bool ok = t < Lin;
+    const int to = t - lh * dil;
+    const bool okz = ok && to >= 0 && to < Lo;
+    const bool okr = ok && t >= dil;
+    const __amdgpu_buffer_rsrc_t rz = brsrc(DZ + (long)b * 32 * Lo, 32 * rowO);
+    const __amdgpu_buffer_rsrc_t rs = brsrc(s_in + (long)b * 32 * Lin, 32 * rowL);
+    const __amdgpu_buffer_rsrc_t rg = brsrc(dS_out + (long)b * 32 * Lo, 32 * rowO);
+    const int offz = okz ? to * 4 : BUF_OOB;
+    const int offs = ok ? t * 4 + 4 * lh * rowL : BUF_OOB;
+    const int offg = okr ? (t - dil) * 4 + 4 * lh * rowO : BUF_OOB;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) dzn[s] = bload(rz, offz, s * rowO);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { svn[r] = bload(rs, offs, mfma32_row(r, 0) * rowL); rvn[r] = bload(rg, offg, mfma32_row(r, 0) * rowO); }
+  };
+  const TileWalk tw = xcd_walk(ntiles);
+  const int first = __builtin_amdgcn_readfirstlane((int)tw.first), last = (int)tw.last, stride = (int)tw.stride;
+  float dza[32], sva[16], rva[16], dzb[32], svb[16], rvb[16];
+  if (first < last) issue(first, dza, sva, rva);
+  for (int i = threadIdx.x; i < 2048; i += 256) wl[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  __syncthreads();
+  float wt[32];  // A[i = c = li][k = (d = s, tap = lh)] = W_dil[d][c][tap]
+#pragma unroll
+  for (int s = 0; s < 32; ++s) wt[s] = wl[s * 65 + li * 2 + lh];
+  auto compute = [&](int tile, const float (&dz)[32], const float (&sv)[16], const float (&rv)[16]) {
+    const int b = tile / tiles_per_seq;
+    const int t = (tile - b * tiles_per_seq) * 32 + li;
+    const __amdgpu_buffer_rsrc_t ro = brsrc(dS_in + (long)b * 32 * Lin, 32 * rowL);
+    const int offs = t < Lin ? t * 4 + 4 * lh * rowL : BUF_OOB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 32; ++s) acc = mfma32(wt[s], dz[s], acc);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bstore((sv[r] > 0.f ? acc[r] : 0.f) + rv[r], ro, offs, mfma32_row(r, 0) * rowL);
+  };
+  for (int tile = first; tile < last; tile += 2 * stride) {
+    issue(tile + stride, dzb, svb, rvb);
+    compute(tile, dza, sva, rva);
+    if (tile + stride >= last) break;
+    issue(tile + 2 * stride, dza, sva, rva);
+    compute(tile + stride, dzb, svb, rvb);
+  }
+}
+
 // HIGH-OCCUPANCY form of (B), the default (see wn_block_fwd_occ): buffer addressing, weights read from LDS per MFMA,
 // nothing held across tiles -> < 128 VGPRs, 4 waves per SIMD.  Same arithmetic, same summation order.
 __global__ void __launch_bounds__(256, 4)
@@ -1951,6 +2015,9 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
         if (blocks > 1024) blocks = 1024;                 // 4 waves per SIMD resident
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
         hipLaunchKernelGGL(wn_block_bwd_dx_occ, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
+      } else if (buf_ok(B, Li) && avvad_tune().wn_flat != 1 && avvad_tune().wn_dx != 3) {     // (wn_dx = 3: the flat kernel)
+        if (blocks > 512) blocks = 512;
+        hipLaunchKernelGGL(wn_block_bwd_dx_buf, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);
       } else {
         if (blocks > 512) blocks = 512;
         hipLaunchKernelGGL(wn_block_bwd_dx_mfma, dim3((int)blocks), dim3(256), 0, s, DZ, si, GA, prm->dil_w_h[i], GB, B, Li, dil);

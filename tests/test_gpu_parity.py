@@ -182,6 +182,7 @@ def test_wavenet_golden(name, alt, lib_options):
         lib_options("wn_flat", 2)
     elif alt == 3:
         lib_options("wn_flat", 1)
+        lib_options("wn_dx", 3)
     elif alt == 4:
         lib_options("wn_bwd_t", 3)          # the one-wave-per-SIMD form of the fused backward (picked beside another stream)
     g = load_golden(name)
