@@ -401,6 +401,48 @@ def test_conv2d_fwd_dgrad_wgrad(N, H, W, C, Co, KS, stride, pad):
     _report(tag + " wgrad", dw, ref_dw, 3e-4 if C == 1 else 1e-4, 1e-5)
 
 
+@pytest.mark.parametrize("N,H,W,C,Co,KS,stride,pad", [(64, 17, 17, 64, 64, 3, 1, 1), (48, 17, 17, 64, 128, 3, 2, 1), (96, 9, 9, 128, 128, 3, 1, 1)])
+def test_conv2d_fallback_paths_agree(N, H, W, C, Co, KS, stride, pad, lib_options):
+    """The forms that only other operand sizes / tile counts select give the same BITS as the defaults on the same problem:
+    flat-addressed gathers with validity selects (operands of 2 GiB and more; option no_buf) against the buffer-addressed
+    ones, and the four-wave fix-up kernel (deep splits; option no_fixup1) against the one-wave-per-strip kernel."""
+    import ctypes as Ct
+    from avvad import _lib as L, ops
+    lib = L.lib()
+    st = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(N, H, W, C, Co, KS, stride, pad)
+    Ho = (H + 2 * pad - KS) // stride + 1
+    torch.manual_seed(N + C)
+    x = torch.randn(N, H, W, C, device=DEV)
+    gy = torch.randn(N, Ho, Ho, Co, device=DEV)
+    w = torch.randn(Co, C, KS, KS, device=DEV) / (C * KS * KS) ** 0.5
+    wf = torch.empty(KS * KS * C * Co, device=DEV)
+    wdg = torch.empty(KS * KS * C * Co, device=DEV)
+    L.check(lib.avvad_conv2d_pack_weights(L.ptr(w), L.ptr(wf), L.ptr(wdg), Ct.byref(d), st), "pack")
+    ews = ops.engine_ws(DEV)
+    wsz = ews.numel() * 4
+
+    def run():
+        y = torch.empty(N, Ho, Ho, Co, device=DEV)
+        dx = torch.empty_like(x)
+        dw = torch.empty(KS * KS * C, Co, device=DEV)
+        L.check(lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), Ct.byref(d), L.ptr(ews), wsz, st), "fwd")
+        L.check(lib.avvad_conv2d_dgrad(L.ptr(gy), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 0, L.ptr(ews), wsz, st), "dgrad")
+        L.check(lib.avvad_conv2d_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), Ct.byref(d), L.ptr(ews), wsz, st), "wgrad")
+        torch.cuda.synchronize()
+        return y, dx, dw
+    base = run()
+    lib_options("no_buf", 1)
+    flat = run()
+    lib_options("no_buf", 0)
+    for a, b in zip(base, flat):
+        assert torch.equal(a, b)                       # same arithmetic, different addressing
+    lib_options("no_fixup1", 1)
+    four = run()
+    for a, b, name in zip(base, four, ("fwd", "dgrad", "wgrad")):
+        _report("conv %s: four-wave fix-up vs one wave per strip" % name, b, a, 1e-5, 1e-6)   # (summation order of the slabs differs)
+
+
 # ------------------------------------------------------------------------------------------ trunk
 def _video_state():
     from oracle import resnet18
