@@ -239,10 +239,10 @@ struct Stage {
     for (int i = 0; i < NV; ++i) {
       int xl, kl;
       coord(t, i, xl, kl);
-      if (Op::KCONTIG) {
+      if constexpr (Op::KCONTIG) {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) S[(kl + j) * LD + xl] = st[i][j];
-      } else if (VEC == 4) {
+      } else if constexpr (VEC == 4) {
         *reinterpret_cast<float4*>(S + kl * LD + xl) = make_float4(st[i][0], st[i][1], st[i][2], st[i][3]);
       } else {
         S[kl * LD + xl] = st[i][0];
