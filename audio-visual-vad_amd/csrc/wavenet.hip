@@ -1365,7 +1365,8 @@ __global__ void __launch_bounds__(256)
 }
 
 // HIGH-OCCUPANCY form of the fused pass (option wn_bwd_t = 2): weights read from LDS per MFMA, no cross-tile prefetch -> under
-// 256 registers, two waves per SIMD (two workgroups per CU).
+// 256 registers, two waves per SIMD (two workgroups per CU).  (Tried for the beside-the-trunk case: this body WITH the cross-tile
+// prefetch, 243 registers and no AGPR shuffling, one workgroup per CU -- 0.2-0.5 ms/step slower than the resident-weights form.)
 __global__ void __launch_bounds__(256, 2)
     wn_block_bwd_dz_wgrad_occ(const float* __restrict__ dS, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
                                const float* __restrict__ w_dense, const float* __restrict__ s_in, float* __restrict__ DZ,
