@@ -16,6 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AVVAD_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libavvad_hip.so")
 
 TRUNK_NCONV = 20
+ABI_VERSION = 2          # include/avvad.h AVVAD_ABI_VERSION: the signatures below describe exactly this version
 _ERR = {-1: "AVVAD_EINVAL (bad descriptor / unsupported shape)", -2: "AVVAD_EWORKSPACE (workspace too small)",
         -3: "AVVAD_ELAUNCH (kernel launch failed)"}
 
@@ -136,6 +137,10 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing
             fn.restype = res
             fn.argtypes = args
+        got = handle.avvad_abi_version()
+        if got != ABI_VERSION:       # a stale build would read e.g. the workspace pointer as the stream and fault the GPU
+            raise AvvadError("%s has ABI version %d, this binding expects %d: rebuild it (python __graft_entry__.py)"
+                             % (LIB_PATH, got, ABI_VERSION))
         _lib = handle
     return _lib
 

@@ -68,15 +68,32 @@ class BucketReducer:
     complete from the END of the buffer towards its start.  With ``names`` (``model.named_parameters()`` order) a bucket
     is also closed where the top-level sub-module changes (``features`` | ``wavenet_en`` | ``lstm_*`` | ``vad_*``) once
     it holds ``min_group_bytes``: the head's buckets then never wait for trunk gradients and overlap the whole trunk
-    backward.  Parameters that received no gradient in the previous step (the reference's unused ``bn`` of
-    ``AV_Net.py:33``, frozen sub-modules) are dropped from the readiness count, so their bucket still launches from the
-    hooks instead of from ``finish()``."""
+    backward.
 
-    def __init__(self, params, flat_grad, offsets, bucket_bytes=25 << 20, group=None, names=None, min_group_bytes=4 << 20):
+    Parameters without a gradient (the reference's unused ``bn`` of ``AV_Net.py:33``, frozen sub-modules) must not hold
+    their bucket back until ``finish()``.  Which parameters those are is AGREED between the ranks, never decided
+    locally: every ``finish()`` all-reduces a presence bitmap (one float per parameter, asynchronously; it is read at
+    the next ``finish()``, a whole step later, so no step waits for it), and a parameter that NO rank announced stops
+    counting towards its bucket's readiness from the step after.  Such "absent" parameters' slices are cut out of their
+    bucket's collective and reduced by ``finish()`` in collectives of their own -- identical on every rank, after every
+    possible writer -- so one that gets a gradient again on some rank
+    only (a data-dependent branch, an unfrozen module) is still summed correctly and nobody waits in a collective the
+    others never enter.  Rules the caller keeps: ONE ``backward()`` per ``finish()`` (no gradient accumulation over
+    several backward passes: a gradient announced after its bucket went out is reported by every rank at the next
+    ``finish()``), and the flat gradient is zeroed between steps (``FlatAdam.zero_grad``).
+
+    ``force_hooks``: register the hooks / sinks and run the collectives even at world size 1 (a one-GPU box can then
+    execute the RCCL path end to end: ``tests/test_gpu_parity.py::test_rccl_path_on_one_gpu``)."""
+
+    def __init__(self, params, flat_grad, offsets, bucket_bytes=25 << 20, group=None, names=None, min_group_bytes=4 << 20,
+                 force_hooks=False):
         self.flat_grad = flat_grad
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_hooks and dist.is_initialized())
         self.params = list(params)             # keep the objects alive: the maps below are keyed by id()
+        self.offsets = list(offsets)
+        self.index = {id(p): i for i, p in enumerate(self.params)}
         self.buckets = []                      # (start, end, n_params)
         self.param_bucket = {}
         tops = [n.split(".")[0] for n in names] if names is not None else None
@@ -91,18 +108,20 @@ class BucketReducer:
             if size >= bucket_bytes or group_edge or last:
                 self.buckets.append((start, end, count))
                 start, count = end, 0
-        self.expected = [b[2] for b in self.buckets]    # parameters a bucket waits for (absent ones removed)
-        self.absent = set()                    # id(p) of parameters that got no gradient last step
+        self.expected = [b[2] for b in self.buckets]    # parameters a bucket waits for (agreed-absent ones removed)
+        self.absent = set()                    # parameter indices no rank announced in the last agreed step
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)
         self.handles = []
         self._hooks = []
         self._names = dict(zip(map(id, self.params), names)) if names is not None else {}
         self._seen = set()
+        self._error = ""                       # a protocol violation seen on THIS rank in the current step
+        self._meta = None                      # (handle, device tensor, host tensor, event) of the previous finish()
         self._sink = None
         self._trace = bool(os.environ.get("AVVAD_DP_TRACE"))      # debug aids, read once
         self._late = bool(os.environ.get("AVVAD_DP_LATE"))
-        if self.world > 1:
+        if self.active:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
             try:                      # gradients written in place by the HIP backward bypass autograd's hooks
@@ -134,55 +153,122 @@ class BucketReducer:
         autograd's post-accumulate hook and/or by the HIP backward's in-place sinks: a parameter written in place can be
         announced by BOTH (observed on torch 2.10: the hook also fires for the ``None`` the Function returns), so
         repeats within a step are dropped -- counting them launched a bucket's all-reduce before its last gradients
-        existed (caught by tests/test_gpu_parity.py::test_two_rank_gpu_data_parallel_step).  Assumes what holds for these
-        models: every parameter is written by exactly one backward Function per step (no gradient accumulation over
-        several backward() calls between two finish() calls: that raises below instead of reducing too early)."""
+        existed (caught by tests/test_gpu_parity.py::test_two_rank_gpu_data_parallel_step).  Never raises (an exception
+        inside an autograd hook on ONE rank would leave its peers waiting in a collective): violations are recorded and
+        reported by every rank together at the next finish()."""
         if id(p) not in self.param_bucket or id(p) in self._seen:
             return
         self._seen.add(id(p))
+        if self.index[id(p)] in self.absent:   # agreed absent: reduced on its own by finish(), whoever has a gradient
+            return
         b = self.param_bucket[id(p)]
-        if id(p) in self.absent:               # came back (e.g. unfrozen): wait for it again from now on
-            self.absent.discard(id(p))
-            self.expected[b] += 1
         if self.launched[b]:
-            raise RuntimeError("BucketReducer: gradient of %s announced after its bucket was all-reduced (a parameter that "
-                               "had no gradient in the previous step got one now, or backward() ran twice before finish())"
-                               % self._names.get(id(p), tuple(p.shape)))
+            self._error = ("gradient of %s announced after its bucket was all-reduced (backward() ran twice before finish()?)"
+                           % (self._names.get(id(p), tuple(p.shape)),))
+            return
         self.pending[b] += 1
         if self._trace:
             print("[dp] grad ready: param %s shape %s -> bucket %d pending %d/%d" % (self._names.get(id(p), "?"), tuple(p.shape), b, self.pending[b], self.expected[b]), flush=True)
         if self.pending[b] == self.expected[b] and not self._late:
             self._launch(b)
 
-    def _launch(self, b):
-        if self.launched[b]:
-            return
-        s, e, _ = self.buckets[b]
-        self.launched[b] = True
+    def _join_streams(self):
+        """A bucket can hold gradients written on different HIP streams (the audio encoder's backward runs on the side
+        stream, ops.side_stream()); a collective is ordered after the CURRENT stream only, so make that stream wait for
+        everything the others have been given so far (all of the slice's writers are enqueued by now)."""
         if self.flat_grad.is_cuda:
-            # A bucket can hold gradients written on different HIP streams (the audio encoder's backward runs on the
-            # side stream, ops.side_stream()); the collective is ordered after the CURRENT stream only, so make that
-            # stream wait for everything the others have been given so far (all of this bucket's writers are enqueued).
             from . import ops
             cur = torch.cuda.current_stream()
             for st in ops.side_streams() + [torch.cuda.default_stream()]:
                 if st != cur:
                     cur.wait_stream(st)
+
+    def _reduce(self, s, e):
         self.handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
+    def _launch(self, b):
+        if self.launched[b]:
+            return
+        self.launched[b] = True
+        self._join_streams()
+        for s, e in self._segments(b):
+            self._reduce(s, e)
+
+    def _segments(self, b):
+        """Bucket b's range of the flat buffer WITHOUT the slices of agreed-absent parameters (finish() reduces those on
+        their own, after every possible writer; reduced here as well they would be summed twice)."""
+        s, e, _ = self.buckets[b]
+        if not self.absent:
+            return [(s, e)]
+        segs, cur = [], s
+        for i in sorted(self.absent):
+            if self.param_bucket[id(self.params[i])] != b:
+                continue
+            if self.offsets[i] > cur:
+                segs.append((cur, self.offsets[i]))
+            cur = self.offsets[i + 1]
+        if e > cur:
+            segs.append((cur, e))
+        return segs
+
+    def _agree(self):
+        """Read the presence bitmap the PREVIOUS finish() all-reduced: the same numbers on every rank."""
+        if self._meta is None:
+            return
+        handle, dev_t, host_t, evt = self._meta
+        self._meta = None
+        handle.wait()
+        if evt is not None:
+            evt.synchronize()
+        counts = host_t if host_t is not None else dev_t
+        if float(counts[-1]) > 0:
+            raise RuntimeError("BucketReducer: a rank reported a protocol violation in the previous step (%s)"
+                               % (getattr(self, "_last_error", "") or "on another rank: see its log"))
+        absent = {i for i in range(len(self.params)) if float(counts[i]) == 0.0}
+        if absent != self.absent:
+            self.absent = absent
+            self.expected = [b[2] for b in self.buckets]
+            for i in absent:
+                self.expected[self.param_bucket[id(self.params[i])]] -= 1
+
     def finish(self):
-        """Call after backward: launches whatever did not fire (parameters without a gradient this step)
-        and waits for every bucket."""
-        if self.world > 1:
+        """Call after backward: launches whatever did not fire, reduces the agreed-absent parameters' slices, waits for
+        every collective and sends this step's presence bitmap on its way."""
+        if self.active:
+            stale_error = self._error
             for b in range(len(self.buckets)):
                 self._launch(b)
+            # agreed-absent parameters: their own collectives (contiguous runs coalesced), the same on every rank
+            run = None
+            for i in sorted(self.absent) + [None]:
+                if run is not None and (i is None or i != run[1] + 1):
+                    self._join_streams()
+                    self._reduce(self.offsets[run[0]], self.offsets[run[1] + 1])
+                    run = None
+                if i is not None:
+                    run = (i, i) if run is None else (run[0], i)
             for h in self.handles:
                 h.wait()
-            # parameters nobody announced this step stop counting towards their bucket's readiness
+            self._agree()                      # (the previous step's bitmap: long complete)
+            meta = torch.zeros(len(self.params) + 1, dtype=torch.float32)
             for p in self.params:
-                if id(p) not in self._seen and id(p) not in self.absent:
-                    self.absent.add(id(p))
-                    self.expected[self.param_bucket[id(p)]] -= 1
+                if id(p) in self._seen:
+                    meta[self.index[id(p)]] = 1.0
+            meta[-1] = 1.0 if stale_error else 0.0
+            self._last_error, self._error = stale_error, ""
+            dev_t = meta.to(self.flat_grad.device)
+            handle = dist.all_reduce(dev_t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            host_t = evt = None
+            if dev_t.is_cuda:
+                handle.wait()                  # stream-orders the copy behind the collective; the host does not block
+                host_t = torch.empty(meta.shape, dtype=torch.float32, pin_memory=True)
+                host_t.copy_(dev_t, non_blocking=True)
+                evt = torch.cuda.Event()
+                evt.record()
+            self._meta = (handle, dev_t, host_t, evt)
+        elif self._error:
+            msg, self._error = self._error, ""
+            raise RuntimeError("BucketReducer: " + msg)
         self.handles = []
         self.pending = [0] * len(self.buckets)
         self.launched = [False] * len(self.buckets)

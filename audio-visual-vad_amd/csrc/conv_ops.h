@@ -61,7 +61,8 @@ static inline TapDiv tap_div(int T, int KS) { return TapDiv{div_magic((unsigned)
 // ---- forward A: rows = output pixels, K = (kh,kw,c), c contiguous (16-byte loads)
 // Context per staged vector: the BYTE offset of (window origin, channel kin) and one validity bit per tap.  A K tile is
 // one tap of one 32-channel chunk (wave-uniform), so load() adds a scalar tap offset and tests one bit.
-// (host: the activation tensor is < 4 GiB -- 32-bit byte offsets -- and KS*KS <= 32)
+// (host, trunk.hip conv_fwd_t / conv_dgrad_t: the activation tensor is < 4 GiB -- 32-bit byte offsets -- and KS*KS <= 32,
+//  one tap-validity bit each; larger kernels are refused with AVVAD_EINVAL)
 template <bool BUF>
 struct Im2colFwd {
   static constexpr bool KCONTIG = true;
@@ -80,7 +81,9 @@ struct Im2colFwd {
     const int n = m / hw, r = m - n * hw;
     const int ho = r / g.Wo, wo = r - ho * g.Wo;
     const int hi0 = ho * g.stride - g.pad, wi0 = wo * g.stride - g.pad;
-    c.boff = (unsigned)((((n * g.H + hi0) * g.W + wi0) * g.C + kin) * 4);     // may wrap below zero: used only with a valid tap
+    // (unsigned arithmetic: the sum may wrap below zero for a window that starts in the padding; it is used only with a
+    //  valid tap, whose offset brings it back in range)
+    c.boff = ((((unsigned)n * (unsigned)g.H + (unsigned)hi0) * (unsigned)g.W + (unsigned)wi0) * (unsigned)g.C + (unsigned)kin) * 4u;
     for (int kh = 0; kh < g.KS; ++kh)
       for (int kw = 0; kw < g.KS; ++kw)
         if ((unsigned)(hi0 + kh) < (unsigned)g.H && (unsigned)(wi0 + kw) < (unsigned)g.W) c.mask |= 1u << (kh * g.KS + kw);
@@ -90,7 +93,7 @@ struct Im2colFwd {
     const int T = g.KS * g.KS, q = k0 >> 5;  // wave-uniform (k0 % 32 == 0, C % 32 == 0)
     const int cc = fast_div(q, td.mg_T), tap = q - cc * T;
     const int kh = fast_div(tap, td.mg_KS), kw = tap - kh * g.KS;
-    const unsigned soff = (unsigned)(((kh * g.W + kw) * g.C + cc * 32) * 4);   // scalar
+    const unsigned soff = ((unsigned)(kh * g.W + kw) * (unsigned)g.C + (unsigned)cc * 32u) * 4u;   // scalar
     const bool ok = (c.mask >> tap) & 1u;
     fetch4<BUF>(x, ok ? c.boff + soff : INVALID_OFF(BUF), v);
     CONVOP_RETURN(ok);
@@ -125,8 +128,8 @@ struct Im2colDgrad {
       }
     // stride 1: pixel (hp - kh, wp - kw) = origin (hp, wp) minus the tap; stride 2: the per-tap pixel is not affine in the
     // tap, so the origin keeps (hp, wp) and load() halves the (scalar) tap shift -- valid taps have even hp-kh / wp-kw
-    if (g.stride == 1) c.boff[0] = (unsigned)((((n * g.Ho + hp) * g.Wo + wp) * g.Co + kin) * 4);   // affine in the tap
-    else c.boff[0] = (unsigned)((((n * g.Ho) * g.Wo) * g.Co + kin) * 4);
+    if (g.stride == 1) c.boff[0] = ((((unsigned)n * (unsigned)g.Ho + (unsigned)hp) * (unsigned)g.Wo + (unsigned)wp) * (unsigned)g.Co + (unsigned)kin) * 4u;   // affine in the tap
+    else c.boff[0] = ((unsigned)n * (unsigned)g.Ho * (unsigned)g.Wo * (unsigned)g.Co + (unsigned)kin) * 4u;
     c.boff[1] = (unsigned)(hp * 65536 + wp);
     return c;
   }
@@ -137,10 +140,10 @@ struct Im2colDgrad {
     const bool ok = (c.mask >> tap) & 1u;
     unsigned off;
     if (g.stride == 1) {                   // one add of a scalar: pixel (hp - kh, wp - kw)
-      off = ok ? c.boff[0] + (unsigned)((cc * 32 - (kh * g.Wo + kw) * g.Co) * 4) : INVALID_OFF(BUF);
+      off = ok ? c.boff[0] + ((unsigned)cc * 32u - (unsigned)(kh * g.Wo + kw) * (unsigned)g.Co) * 4u : INVALID_OFF(BUF);
     } else {
       const int ho = ((int)(c.boff[1] >> 16) - kh) >> 1, wo = ((int)(c.boff[1] & 0xffffu) - kw) >> 1;
-      off = ok ? c.boff[0] + (unsigned)(((ho * g.Wo + wo) * g.Co + cc * 32) * 4) : INVALID_OFF(BUF);
+      off = ok ? c.boff[0] + ((unsigned)(ho * g.Wo + wo) * (unsigned)g.Co + (unsigned)cc * 32u) * 4u : INVALID_OFF(BUF);
     }
     fetch4<BUF>(dy, off, v);
     CONVOP_RETURN(ok);

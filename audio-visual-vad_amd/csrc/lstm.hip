@@ -150,8 +150,11 @@ __global__ void __launch_bounds__(1024)
 // holds several per CU).  Workgroup blk owns hidden units 4 blk .. 4 blk + 3 for every sequence (B <= 64); wave w holds
 // the K quarter w of its 16 gate rows of W_hh as MFMA A fragments IN REGISTERS for the whole launch (NK float4 per lane),
 // so W_hh is read once per layer instead of once per step, and a step costs no launch.
-// What carries h_t between workgroups (per-XCD L2s are not coherent): h_t is stored with sc1 (write-through) stores and
-// read with sc1 (L1-bypassing) loads -- rows of y that nobody has read before, so no L2 holds an older copy -- and the
+// What carries h_t between workgroups (per-XCD L2s are not coherent): h_t is stored with sc1 (write-through) stores into
+// one of TWO padded hand-off copies (re-used every second step) and read with sc1 loads.  Correctness of the re-use rests
+// on the sc1 forms: an sc1 store leaves no line behind in the storing XCD's L2 and an sc1 load bypasses the reading CU's
+// L1 and is served from beyond the XCD's L2 for lines that L2 does not hold -- no L2 ever holds a copy of the hand-off
+// buffers, because every access to them in this kernel is an sc1 access (MI355X_MICROARCH "stores of each flavour") -- and the
 // step barrier is one agent-scope atomic add per workgroup (behind s_waitcnt vmcnt(0) of every storing wave and a workgroup
 // barrier) polled by one lane with sc1 loads: MI355X_MICROARCH "Valid forms", first table row.  No agent-scope fences: the
 // release/acquire fences of round 1's persistent attempt wrote back and invalidated whole L2s every step and lost 0.4 ms.
@@ -317,6 +320,27 @@ __global__ void __launch_bounds__(256)
     o[0] = tA; o[1] = tB; o[2] = tC;
   }
 #endif
+}
+
+// Workgroups of lstm_persistent_fwd<NK> the device can hold at once, by the occupancy query (one block per CU taken off
+// where it reports more than one: on ROCm 7.2 the query over-reports by one for SGPR-heavy 256-thread kernels,
+// MI355X_MICROARCH "Residency and cooperative launch").  The grid barrier needs the whole grid resident; a grid beyond
+// this falls back to the per-step kernels.  What the query cannot see is OTHER work on the device (a second process, RCCL's
+// kernels, the trunk's persistent grids on another stream): their workgroups retire on their own -- nothing they wait for
+// is behind this launch -- so the grid still becomes resident, late; the spins are bounded all the same.
+static int persistent_capacity(int NKp) {
+  static int cap[3] = {-1, -1, -1};
+  const int i = NKp == 16 ? 0 : (NKp == 8 ? 1 : 2);
+  if (cap[i] < 0) {
+    int nb = 0, dev = 0, cus = 0;
+    hipError_t e = NKp == 16 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_persistent_fwd<16>, 256, 0)
+                   : NKp == 8 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_persistent_fwd<8>, 256, 0)
+                              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, lstm_persistent_fwd<4>, 256, 0);
+    if (e != hipSuccess || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    cap[i] = (nb > 1 ? nb - 1 : nb) * cus;
+  }
+  return cap[i];
 }
 
 // behind the persistent launch: had a step barrier ever timed out (status word set), the layer's output is poisoned
@@ -509,7 +533,7 @@ extern "C" int avvad_lstm_layer_fwd(const float* x, const float* w_ih, const flo
   const bool persistent = fused_step && !avvad_tune().lstm_no_persistent && B <= 64 && B % 16 == 0 && T > 1 &&
                           (NKp == 16 || NKp == 8 || NKp == 4) && H % 64 == 0 && H / 4 <= 256 &&
                           (long)B * T * H * 4 < (1L << 31);
-  if (persistent) {
+  if (persistent && H / 4 <= persistent_capacity(NKp)) {
     hipLaunchKernelGGL(lstm_gates_fwd, dim3(cdiv(B * H, 256)), dim3(256), 0, s, w.G, w.Cs, y, d->lengths, B, T, H, 0);
     unsigned* sync = reinterpret_cast<unsigned*>(w.slab);          // the engine scratch is idle during the time loop
     if (hipMemsetAsync(sync, 0, 2048, s) != hipSuccess) return AVVAD_ELAUNCH;   // status words + one flag per workgroup

@@ -2,8 +2,7 @@
 #include "common.h"
 
 extern "C" const char* avvad_version(void) { return "avvad-hip 0.1 (gfx950, fp32 MFMA)"; }
-extern "C" int avvad_abi_version(void) {
-  AVVAD_ENTER(); return 1; }
+extern "C" int avvad_abi_version(void) { return AVVAD_ABI_VERSION; }   // include/avvad.h says what changed when
 
 // ---------------------------------------------------------------- schedule options
 #include <stdlib.h>

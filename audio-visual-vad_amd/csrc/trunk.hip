@@ -463,6 +463,11 @@ __global__ void __launch_bounds__(256) stem_wgrad_reduce(const float* __restrict
 
 // ------------------------------------------------------------------ conv launchers
 static inline bool fits_u31(long n) { return n >= 0 && n < (1L << 31); }
+// gathered operands are addressed with 32-bit BYTE offsets (Ctx.boff, fetch4): at most 2^30 floats (4 GiB).  Between the
+// buffer form's 2 GiB limit and this one the flat form serves; beyond it the launchers refuse (AVVAD_EINVAL).
+static inline bool fits_u30(long n) { return n >= 0 && n < (1L << 30); }
+// the im2col gathers keep one tap-validity bit per (kh, kw) in a 32-bit word
+static inline bool taps_fit(const Geom& g) { return g.KS * g.KS <= 32; }
 // operands below 2 GiB take the buffer-addressed gathers (conv_ops.h "BUF")
 static inline bool fits_buf(long n_floats) { return n_floats >= 0 && n_floats < (1L << 29) - 64; }
 template <bool BUF>
@@ -481,8 +486,8 @@ static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, 
     convop::StemFwd a{x, g, M, K};
     return igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s, slab);
   }
-  if (g.C % 32 || g.Co % 4) return AVVAD_EINVAL;
-  if (!fits_u31((long)g.N * g.H * g.W * g.C) || !fits_u31((long)K * g.Co)) return AVVAD_EINVAL;   // 32-bit gather offsets
+  if (g.C % 32 || g.Co % 4 || !taps_fit(g)) return AVVAD_EINVAL;
+  if (!fits_u30((long)g.N * g.H * g.W * g.C) || !fits_u30((long)K * g.Co)) return AVVAD_EINVAL;   // 32-bit BYTE offsets in the gathers
   const int T = g.KS * g.KS;
   convop::ColTapRows<BUF> b{wf, g.Co, g.Co, K, g.C, T, convop::div_magic(T)};
   convop::Im2colFwd<BUF> a{x, g, M, convop::tap_div(T, g.KS)};
@@ -497,8 +502,8 @@ static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hi
 template <bool BUF>
 static int conv_dgrad_t(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
   const int M = g.N * g.H * g.W, K = g.KS * g.KS * g.Co;
-  if (g.Co % 32 || g.C % 4) return AVVAD_EINVAL;
-  if (!fits_u31((long)g.N * g.Ho * g.Wo * g.Co) || !fits_u31((long)K * g.C)) return AVVAD_EINVAL;   // 32-bit gather offsets
+  if (g.Co % 32 || g.C % 4 || !taps_fit(g)) return AVVAD_EINVAL;
+  if (!fits_u30((long)g.N * g.Ho * g.Wo * g.Co) || !fits_u30((long)K * g.C)) return AVVAD_EINVAL;   // 32-bit BYTE offsets in the gathers
   if (g.stride == 2) {
     // parity-class decomposition (conv_ops.h): 4 small GEMMs over live taps only, accumulating into dx
     if (!accumulate) hipLaunchKernelGGL(zero_f32, dim3(ew_grid((long)M * g.C)), dim3(256), 0, s, dx, (long)M * g.C);
@@ -565,7 +570,7 @@ static int conv_wgrad_t(const float* x, const float* dy, float* pk, const Geom& 
   if (g.C % 32) return AVVAD_EINVAL;
   convop::EpiWgrad e{pk, g.Co, nullptr, 0, 1, g.C, g.KS * g.KS, convop::div_magic(g.KS * g.KS)};
   if ((unsigned long)(K + igemm::BK) * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
-  if (!fits_u31((long)g.N * g.H * g.W * g.C)) return AVVAD_EINVAL;                                              // 32-bit gather offsets
+  if (!fits_u30((long)g.N * g.H * g.W * g.C) || !fits_u30((long)K * g.Co)) return AVVAD_EINVAL;                // 32-bit BYTE offsets in the gathers
   convop::WgradX<BUF> a{x, g, M, K, convop::div_magic(g.Ho * g.Wo), convop::div_magic(g.Wo)};
   const bool small = g.Co <= 64;
   const int nb = cdiv(M, 128) * cdiv(g.Co, small ? 64 : 128);

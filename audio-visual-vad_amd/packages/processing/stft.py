@@ -16,7 +16,7 @@ def stft_pytorch(x, fs=16e3, wlen_sec=50e-3, win='hann', hop_percent=0.25, cente
     nfft = int(wlen_sec * fs)
     hopsamp = int(hop_percent * nfft)
     if x.is_cuda:
-        # GPU tensors ALWAYS take the HIP front-end (framing + Hann + DFT as one MFMA GEMM, csrc/stft.hip); a
+        # GPU tensors take the HIP front-end (framing + Hann + DFT as one MFMA GEMM, csrc/stft.hip); a
         # configuration it does not implement is an error, never a silent library call.  center=True is the
         # reference's reflect padding of nfft/2 samples per side, applied (after its end padding) as plain data movement.
         from avvad import ops
@@ -34,21 +34,10 @@ def stft_pytorch(x, fs=16e3, wlen_sec=50e-3, win='hann', hop_percent=0.25, cente
                 x_ = torch.nn.functional.pad(x, (0, hopsamp), mode='constant')
         x_ = torch.nn.functional.pad(x_.view(1, 1, -1), (nfft // 2, nfft // 2), mode=pad_mode).view(-1)
         return ops.stft(x_, nfft, hopsamp, mode=2, pad_at_end=False, fs=fs)
-    # host tensors: the reference's own call (a torch.stft wrapper run by its CPU data pipeline), kept for data prep
-    x_ = x
-    if pad_at_end:
-        n_hops = len(x) / fs / wlen_sec / hop_percent
-        if math.ceil(n_hops) != int(n_hops):
-            x_ = torch.nn.functional.pad(x, (0, hopsamp), mode='constant')
-    if isinstance(win, str):
-        if win != 'hann':
-            raise ValueError("only the Hann window is supported")
-        window = torch.hann_window(window_length=nfft, device=x.device)
-    else:
-        window = win
-    S = torch.stft(input=x_, n_fft=nfft, hop_length=hopsamp, win_length=None, window=window, center=center,
-                   pad_mode=pad_mode, return_complex=True)
-    return torch.view_as_real(S)
+    # host tensors: like every other op of the path there is no CPU / PyTorch fallback; the CPU restatement
+    # of this function lives in oracle/frontend.py (test infrastructure)
+    from avvad._lib import AvvadError
+    raise AvvadError("stft_pytorch: x must be a GPU tensor -- the AV-VAD front-end has no CPU fallback")
 
 
 def log_power_spectrogram(x, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, eps=1e-8, pad_at_end=True):

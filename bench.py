@@ -45,6 +45,7 @@ W0 = w0(T_FRAMES)
 PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0     # HBM3E spec (6.29 TB/s measured copy)
+RESERVE_CUS_DP = 16       # N > 1: CUs the persistent conv grids leave to RCCL's channel workgroups
 # rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_summary.py -> profiles/r02_pmc_*_per_kernel.csv);
 # FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> doubled.  Bytes per launch of the two roofline kernels.
 TRAFFIC = {"conv_fwd": None, "wn_layer": None}
@@ -273,19 +274,76 @@ def parity_probe(torch, model):
     return float((y.detach().cpu() - ref).abs().max())
 
 
+def bench_c1(args):
+    """BASELINE configs[0]: the audio_net WaveNet-encoder forward on the CPU, one 16000-sample chunk, batch 1, through the
+    evaluate_audio_net.process_utt-shaped plumbing (peak-normalise -> encoder -> (1,60,Bn) -> 2xLSTM(1024) -> FC -> sigmoid ->
+    threshold).  The reference's own CPU-runnable case: timed on the oracle (a restatement of the reference's PyTorch-CPU
+    arithmetic), cores stated; where a GPU is present the same chunk also runs through the HIP path and the max |delta| of
+    the logits is reported beside it."""
+    import torch
+    from oracle import models
+    from packages.models.Audio_Net import DeepVAD_audio
+    cores = min(len(os.sched_getaffinity(0)), 16)
+    torch.set_num_threads(cores)
+    cfg = w0(60)
+    torch.manual_seed(0)
+    m = DeepVAD_audio(2, 1024, 1, wavenet_params=cfg)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1234)
+    wave = torch.rand(1, 1, 16000, generator=g) * 2 - 1
+
+    def cpu_fwd():
+        with torch.no_grad():
+            x = wave / wave.abs().amax(dim=2, keepdim=True)                    # evaluate_audio_net.py:125-127
+            y = models.audio_net(sd, x, [60], 2, wavenet_cfg=cfg)               # encoder -> (1,60,Bn) -> LSTM -> FC
+            return y, (torch.sigmoid(y) > 0.5)                                 # :236-250 soft / hard decisions
+    times = []
+    for _ in range(args.warmup + max(5, args.steps)):
+        t0 = time.perf_counter()
+        y_ref, _ = cpu_fwd()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[args.warmup:])[len(times[args.warmup:]) // 2]
+    out = {"metric": "audio_net WaveNet-encoder forward on CPU (frames/s)", "value": round(60 / t, 1), "unit": "frames/s", "n_gpus": 0,
+           "steps": len(times) - args.warmup, "warmup": args.warmup, "ms_per_step": round(1e3 * t, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "BASELINE configs[0]: audio_net (WaveNet-W0 encoder P=60 + 2xLSTM1024 + FC) forward on one 16000-sample "
+                                  "chunk, batch 1, evaluate_audio_net.process_utt plumbing, CPU oracle (kind: port)", "name": "c1",
+                      "cores": cores, "samples": 16000, "frames": 60}}
+    if torch.cuda.is_available():
+        mg = m.to("cuda:0").eval()
+        wg = wave.to("cuda:0")
+        from avvad import ops
+
+        def gpu_fwd():
+            with torch.no_grad():
+                return mg(ops.peak_normalize(wg.view(1, -1)).view(1, 1, -1), [60])
+        y = gpu_fwd()
+        torch.cuda.synchronize()
+        ms = _events(torch, gpu_fwd, 20)
+        out["gpu"] = {"ms": round(ms, 3), "frames_per_s": round(60 / ms * 1e3, 1),
+                      "cpu_ref_max_abs_delta": float((y.cpu() - y_ref).abs().max())}
+    print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", choices=sorted(CONFIGS), default="c4")
+    ap.add_argument("--config", choices=sorted(CONFIGS) + ["c1"], default="c4")
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the MEDIAN block is reported")
+    ap.add_argument("--global-frame-pairs", type=int, default=0, help="c4 only: fix the GLOBAL batch (BASELINE configs[3]: 1024 over 2 and 4 "
+                    "GPUs) and shard it over the ranks -- strong scaling; default: 1024 frame-pairs PER GPU (weak scaling)")
     ap.add_argument("--forward-only", action="store_true", help="inference forward instead of the training step")
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32", help="bf16: BASELINE configs[4] arithmetic (own line, never the headline)")
-    ap.add_argument("--reserve-cus", type=int, default=0, help="CUs left free by the persistent conv grids (room for RCCL kernels at N>1)")
+    ap.add_argument("--reserve-cus", type=int, default=-1, help="CUs left free by the persistent conv grids (room for RCCL kernels); "
+                    "default: 0 on one GPU, %d at N > 1 (DESIGN.md 5)" % RESERVE_CUS_DP)
     ap.add_argument("--no-extras", action="store_true", help="skip roofline / cpu_baseline / parity probes")
     ap.add_argument("--ab", default="", help="tuning aid: after the timed region, time the step under library option NAME=VALUE\n"
                     "against its current value, A/B/A/B in this process (stderr; boxes differ by several %)")
     args = ap.parse_args()
+    if args.config == "c1":
+        return bench_c1(args)
 
     import torch
     import torch.distributed as dist
@@ -303,13 +361,18 @@ def main():
                          % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if args.reserve_cus:
-        L.set_option("max_cus", 256 - args.reserve_cus)
+    reserve = args.reserve_cus if args.reserve_cus >= 0 else (RESERVE_CUS_DP if world > 1 else 0)
+    if reserve:
+        L.set_option("max_cus", 256 - reserve)
     if args.dtype == "bf16":
         if L.lib().avvad_set_option(b"bf16", 1) != 0:
             raise SystemExit("this build of libavvad_hip.so has no bf16 path")
 
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config])
+    if args.global_frame_pairs:
+        if args.config != "c4" or args.global_frame_pairs % (cfg["T"] * world):
+            raise SystemExit("--global-frame-pairs: c4 only, and a multiple of %d x the number of GPUs" % cfg["T"])
+        cfg["n_seq"] = args.global_frame_pairs // (cfg["T"] * world)
     kind, n_seq, T = cfg["kind"], cfg["n_seq"], cfg["T"]
     torch.manual_seed(0)                       # identical initial weights on every rank
     if kind == "av":
@@ -357,22 +420,30 @@ def main():
         step()
     torch.cuda.synchronize()
     log("warm-up done")
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    # --blocks timed blocks of EXACTLY --steps steps each, every one bracketed by a barrier + synchronize on both sides and
+    # taken as the MAX over ranks; the MEDIAN block is the reported one (a single 0.4 s region let box-to-box and
+    # clock-ramp noise of a few % decide the headline).
+    block_dt = []
+    for blk in range(max(1, args.blocks)):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        block_dt.append(dt)
+        log("timed block %d: %.3f s for %d steps" % (blk, dt, args.steps))
+    dt = sorted(block_dt)[len(block_dt) // 2]
     final_loss = float(loss.item())
-    log("timed region: %.3f s for %d steps" % (dt, args.steps))
+    log("timed region (median block): %.3f s for %d steps" % (dt, args.steps))
     if args.ab and world == 1:
         from avvad import _lib as L_
         name, val = args.ab.split("=")
@@ -400,14 +471,16 @@ def main():
         out = {"metric": "AV frame-pairs/sec (%s)" % mode if kind == "av" else "%s_net frames/sec (%s)" % (kind, mode),
                "value": round(fp_per_step * args.steps / dt, 1),
                "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(1e3 * t_step, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(1e3 * t_step, 3), "higher_is_better": True,
+               "scaling": "strong" if args.global_frame_pairs else "weak",
                "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": cfg["what"] if not args.forward_only else
                           cfg["what"].replace("training step", "inference forward").replace(", masked BCE, backward, RCCL all-reduce, fused Adam", "")
                           .replace(", masked BCE, backward, fused Adam", ""),
                           "name": args.config, "per_gpu_frame_pairs": n_seq * T, "global_frame_pairs": fp_per_step,
                           "sequences_per_gpu": n_seq, "frames_per_sequence": T, "samples_per_sequence": cfg["L"],
-                          "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4),
+                          "parallelism": "dp%d" % world, "final_loss": round(final_loss, 4), "reserved_cus": reserve,
+                          "timed_blocks_ms_per_step": [round(1e3 * b / args.steps, 3) for b in block_dt], "reported_block": "median",
                           # whole-step fractions of SURVEY 8d (per GPU): algorithmic FLOPs / layer-at-a-time bytes over the step time
                           "flop_frac": round(flops / t_step / 1e12 / peak, 4), "hbm_frac": round(byts / t_step / 1e9 / PEAK_HBM_GBS, 4),
                           "algorithmic_tflop_per_step": round(flops / 1e12, 4), "layerwise_gb_per_step": round(byts / 1e9, 3)}}
@@ -418,7 +491,8 @@ def main():
             if hb is not None:
                 out["roofline_hbm" if "roofline" in out else "roofline"] = hb
             log("roofline probes done")
-            if world == 1 and kind == "av" and args.dtype == "f32":     # CPU baseline and CPU-reference delta: rank 0 at N=1 only
+            if world == 1 and kind == "av":     # CPU baseline and CPU-reference delta: rank 0 at N=1 only
+                # (bf16: the delta of the bf16 arithmetic to the fp32 CPU reference, BASELINE configs[4]'s own tolerance applies)
                 out["cpu_ref_max_abs_delta"] = parity_probe(torch, model)
                 log("parity probe done")
                 out["cpu_baseline"] = cpu_baseline(torch)

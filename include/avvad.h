@@ -37,7 +37,10 @@ typedef void* avvad_stream_t; /* hipStream_t */
 #define AVVAD_EWORKSPACE (-2) /* workspace too small */
 #define AVVAD_ELAUNCH (-3)    /* hipGetLastError() != hipSuccess after a launch */
 
-/* library / build identification ("gfx950", ABI version) */
+/* library / build identification ("gfx950", ABI version).  AVVAD_ABI_VERSION is what THIS header describes; a binding
+ * must refuse a library whose avvad_abi_version() differs (signatures changed incompatibly between versions:
+ * 2 = (ws, ws_bytes) in front of the stream of avvad_gemm_f32 / avvad_conv2d_*, avvad_wavenet_desc.shared_device). */
+#define AVVAD_ABI_VERSION 2
 const char* avvad_version(void);
 int avvad_abi_version(void);
 

@@ -1,6 +1,7 @@
 """CPU tests of the host side: the C-ABI library loads and exports every declared symbol (no compute calls
 without a GPU), the drop-in classes keep the reference's state_dict keys, host logic (collates, STFT front-end,
 metrics), the product path refuses to run without a GPU, and the N>1 data-parallel reducer on gloo."""
+import json
 import os
 import re
 import socket
@@ -20,7 +21,7 @@ T = torch.from_numpy
 def test_library_loads_and_exports_every_declared_symbol():
     from avvad import _lib as L
     h = L.lib()
-    assert b"gfx950" in h.avvad_version() and h.avvad_abi_version() == 1
+    assert b"gfx950" in h.avvad_version() and h.avvad_abi_version() == L.ABI_VERSION == 2
     header = open(os.path.join(ROOT, "include", "avvad.h")).read()
     declared = set(re.findall(r"\b(avvad_[a-z0-9_]+)\s*\(", header))
     assert declared == set(L.SIGNATURES), declared ^ set(L.SIGNATURES)
@@ -203,11 +204,12 @@ def test_stft_frontend_and_metrics_host_side():
     from packages.models.utils import batch_f1, f1_loss
     from packages.processing.stft import log_power, stft_pytorch
     x = stategen.rand(90, 16000, scale=0.3)
-    S = stft_pytorch(x, fs=16e3, wlen_sec=64e-3, win='hann', hop_percent=0.25, center=False, pad_at_end=True)
+    from avvad import AvvadError
+    with pytest.raises(AvvadError):          # host tensors: no CPU / PyTorch fallback, like every other op of the path
+        stft_pytorch(x, fs=16e3, wlen_sec=64e-3, win='hann', hop_percent=0.25, center=False, pad_at_end=True)
     ref = frontend.stft(x, fs=16e3, wlen_sec=64e-3, hop_percent=0.25, center=False, pad_at_end=True)
-    assert S.shape == (513, 60, 2)
-    np.testing.assert_array_equal(S.numpy(), ref.numpy())
-    np.testing.assert_array_equal(log_power(S).numpy(), frontend.log_power(ref).numpy())
+    assert ref.shape == (513, 60, 2)
+    np.testing.assert_array_equal(log_power(ref).numpy(), frontend.log_power(ref).numpy())
     with pytest.raises(ValueError):
         stft_pytorch(x, fs=16e3, wlen_sec=50.01e-3)
     g = load_golden("misc")
@@ -325,34 +327,83 @@ def test_bucket_reducer_counts_each_parameter_once_per_step():
     assert red.pending[0] == 1
 
 
-def test_bucket_reducer_groups_absent_parameters_and_close():
-    """Buckets break where the top-level sub-module changes; a parameter that got no gradient in a step (the
-    reference's unused ``bn``) stops counting towards its bucket's readiness; announcing a gradient after its bucket
-    went out raises; close() detaches the reducer from the global gradient sinks."""
+def _dp_absent_worker(rank, world, port, out):
+    """Manual 'backward' on CPU tensors: announce gradients in reverse order, as the hooks would."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "audio-visual-vad_amd"), os.path.join(ROOT, "tests")]
+    import torch.distributed as dist
     from avvad import dist as avd
-    from avvad import ops
+    avd.init_from_env("gloo")
     names = ["features.0.weight", "features.1.weight", "bn.weight", "lstm.w", "lstm.b", "vad.weight"]
-    ps = [torch.nn.Parameter(torch.randn(n)) for n in (4000, 3000, 10, 5000, 100, 7)]
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (4000, 3000, 10, 5000, 100, 7)]
     flat, offsets = avd.flat_views(ps)
     red = avd.BucketReducer(ps, flat, offsets, bucket_bytes=1 << 30, names=names, min_group_bytes=1 << 10)
-    # features | bn (too small: rides with lstm) + lstm | vad (last)
-    assert [b[2] for b in red.buckets] == [2, 3, 1], red.buckets
-    red.world = 2                                              # pretend: exercise the bookkeeping without a process group
-    launched = []
-    red._launch = lambda b: None if red.launched[b] else (launched.append(b), red.launched.__setitem__(b, True))
-    for p in (ps[5], ps[4], ps[3], ps[1], ps[0]):              # backward order; bn.weight never shows up
-        red._on_grad(p)
-    assert launched == [2, 0]
-    red.handles = []
-    red.finish()                                               # launches bucket 1, learns that bn.weight is absent
-    assert launched == [2, 0, 1] and red.expected == [2, 2, 1] and id(ps[2]) in red.absent
-    launched.clear()
-    for p in (ps[5], ps[4], ps[3]):
-        red._on_grad(p)
-    assert launched == [2, 1]                                  # now the middle bucket goes out from the hooks
-    with pytest.raises(RuntimeError):
-        red._on_grad(ps[2])                                    # late gradient for an already reduced bucket
-    red.finish()
+    assert [b[2] for b in red.buckets] == [2, 3, 1], red.buckets     # features | bn (too small: rides with lstm) + lstm | vad
+    val = lambda r, k, i: float((r + 1) * 100 + k * 10 + i)
+    log = []
+
+    def step(k, present_by_rank, early_check=None, double=None):
+        flat.zero_()
+        for i in (5, 4, 3, 2, 1, 0):                              # backward order
+            if i in present_by_rank[rank]:
+                ps[i].grad.add_(val(rank, k, i))
+                red._on_grad(ps[i])
+        if early_check is not None:
+            log.append((k, "launched_before_finish", list(red.launched)))
+        if double is not None and rank == double:                  # a second backward() before finish(), on one rank only
+            red._seen.discard(id(ps[0]))
+            red._on_grad(ps[0])
+        red.finish()
+        for i in range(6):
+            want = sum(val(r, k, i) for r in range(world) if i in present_by_rank[r])
+            got = flat[offsets[i]:offsets[i] + ps[i].numel()]
+            assert float((got - want).abs().max()) == 0.0, (rank, k, i, float(got[0]), want)
+
+    allp = {0, 1, 3, 4, 5}
+    step(0, [allp, allp], early_check=True)       # nothing agreed yet: the middle bucket waits for bn.weight until finish()
+    step(1, [allp, allp], early_check=True)       # finish(1) reads step 0's bitmap: bn.weight is absent on every rank
+    assert red.absent == {2} and red.expected == [2, 2, 1]
+    step(2, [allp, allp], early_check=True)       # now the middle bucket goes out from the hooks
+    step(3, [allp, allp | {2}])                   # bn.weight comes back on rank 1 ONLY: still summed correctly, nobody hangs
+    step(4, [allp | {2}, allp | {2}])             # (finish(4) reads step 3's bitmap: present somewhere -> counted again)
+    assert red.absent == set() and red.expected == [2, 3, 1]
+    step(5, [allp | {2}, allp | {2}], early_check=True)
+    step(6, [allp | {2}, allp | {2}], double=0)   # protocol violation on rank 0 only: no exception inside the hook ...
+    raised = False
+    try:
+        step(7, [allp | {2}, allp | {2}])         # ... every rank reports it at the next finish()
+    except RuntimeError as e:
+        raised = "protocol violation" in str(e)
+    log.append(("raised", raised))
+    with open(out + ".%d" % rank, "w") as f:
+        json.dump(log, f)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_dp_absent_parameters_are_agreed_between_ranks(tmp_path):
+    """Which parameters have no gradient is agreed between the ranks through an all-reduced presence bitmap (never decided
+    locally): buckets stop waiting for them, a parameter that comes back on ONE rank only is still reduced by every rank,
+    and a double backward() on one rank is reported by all ranks together instead of hanging the others."""
+    out = str(tmp_path / "log")
+    mp.spawn(_dp_absent_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for r in range(2):
+        with open(out + ".%d" % r) as f:
+            log = json.load(f)
+        d = {(e[0], e[1]) if len(e) == 3 else e[0]: e[-1] for e in log}
+        assert d[(0, "launched_before_finish")] == [True, False, True]
+        assert d[(1, "launched_before_finish")] == [True, False, True]
+        assert d[(2, "launched_before_finish")] == [True, True, True]
+        assert d[(5, "launched_before_finish")] == [True, True, True]
+        assert d["raised"] is True
+
+
+def test_bucket_reducer_close_detaches_the_gradient_sink():
+    from avvad import dist as avd
+    from avvad import ops
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (40, 30)]
+    flat, offsets = avd.flat_views(ps)
+    red = avd.BucketReducer(ps, flat, offsets)
     red.world = 1
     red._sink = red._on_grad
     ops.GRAD_SINKS.append(red._sink)

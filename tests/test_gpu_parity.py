@@ -169,7 +169,8 @@ def test_engine_cu_cap_option(lib_options):
 # ------------------------------------------------------------------------------------------ WaveNet encoder
 @pytest.mark.parametrize("name,alt", [("wn_tiny", 0), ("wn_fw3_qc2", 0), ("wn_nobias", 0), ("wn_w0", 0), ("wn_w0_t16", 0),
                                       ("wn_nobias", 1), ("wn_w0", 1), ("wn_w0_t16", 1), ("wn_w0", 2), ("wn_w0_t16", 2),
-                                      ("wn_nobias", 3), ("wn_w0", 3), ("wn_nobias", 4), ("wn_w0", 4), ("wn_w0_t16", 4)])
+                                      ("wn_nobias", 3), ("wn_w0", 3), ("wn_nobias", 4), ("wn_w0", 4), ("wn_w0_t16", 4),
+                                      ("wn_w0_t16", 5), ("wn_fw3_qc2", 5)])
 def test_wavenet_golden(name, alt, lib_options):
     """alt=1: the alternate block backward kept in the library (transposed products, no LDS transposes); alt=2: the kernel
     forms picked beside another stream (dx with resident weights, forward with resident weights + cross-tile prefetch);
@@ -185,6 +186,11 @@ def test_wavenet_golden(name, alt, lib_options):
         lib_options("wn_dx", 3)
     elif alt == 4:
         lib_options("wn_bwd_t", 3)          # the one-wave-per-SIMD form of the fused backward (picked beside another stream)
+    elif alt == 5:
+        # option bf16 (BASELINE configs[4]): the R = D = 32 block kernels of W0 are fp32-MFMA kernels of their own and do not
+        # change; shapes that go through the GEMM engine (fw = 3, qc = 2: the Conv1d weight gradients) multiply bf16-rounded
+        # operands there.  Stated tolerance for those gradients: relative L2 <= 1e-2 (2^-8 per operand, random signs).
+        lib_options("bf16", 1)
     g = load_golden(name)
     cfg = wn_cfg_from(g)
     m = wavenet_autoencoder(**cfg)
@@ -194,9 +200,10 @@ def test_wavenet_golden(name, alt, lib_options):
     y = m(x)
     _report(name + " forward", y, g["y"], 1e-4)
     (y * T(g["G"]).to(DEV)).sum().backward()
-    _report_grad(name + " d/dx", x.grad, g["dx"])
+    rb = 1e-2 if alt == 5 else 2e-3
+    _report_grad(name + " d/dx", x.grad, g["dx"], rel_bound=rb)
     for k, p in m.named_parameters():
-        _report_grad(name + " d/d" + k, p.grad, g["g." + k])
+        _report_grad(name + " d/d" + k, p.grad, g["g." + k], rel_bound=rb)
 
 
 def test_wavenet_backward_is_bit_reproducible():
@@ -686,8 +693,9 @@ def test_training_steps_match_cpu_adam():
     assert p0.grad.data_ptr() >= opt.flat_grad.data_ptr() and p0.grad.data_ptr() < opt.flat_grad.data_ptr() + 4 * opt.flat_grad.numel()
 
 
-def test_av_training_is_bit_reproducible():
-    """Two trainings from the same initial state (W0 encoder, ResNet-18 trunk, 2 x LSTM(1024), FC; 16 sequences x 16
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_av_training_is_bit_reproducible(dtype, lib_options):
+    """(bf16: the same under BASELINE configs[4]'s arithmetic.)  Two trainings from the same initial state (W0 encoder, ResNet-18 trunk, 2 x LSTM(1024), FC; 16 sequences x 16
     frame-pairs; 2 Adam steps, the encoder on its side stream) end in the SAME BITS: no kernel of the step adds in arrival
     order (stream-K fix-up, BatchNorm's two-stage sums, the encoder's slab reductions, one-block loss)."""
     import copy
@@ -696,6 +704,8 @@ def test_av_training_is_bit_reproducible():
     from packages.models.utils import batch_binary_cross_entropy
     wcfg = dict(filter_width=2, quantization_channel=1, dilations=[2 ** i for i in range(10)] * 2, en_residual_channel=32,
                 en_dilation_channel=32, en_bottleneck_width=256, en_pool_kernel_size=16, use_bias=True)
+    if dtype == "bf16":
+        lib_options("bf16", 1)
     torch.manual_seed(3)
     m0 = DeepVAD_AV(2, 1024, 1, wavenet_params=wcfg)
     B, Tn = 16, 16
@@ -747,6 +757,9 @@ def test_stft_frontend_gpu(L):
 
 
 # ------------------------------------------------------------------------------------------ bf16 arithmetic (BASELINE configs[4])
+BF16_GRAD_REL = {"head": 5e-2, "encoder": 1e-1, "trunk": 3e-1}      # relative L2 of a gradient tensor vs the fp32 oracle
+
+
 @pytest.mark.parametrize("N,H,W,C,Co,KS,stride,pad", [(3, 17, 17, 64, 64, 3, 1, 1), (2, 17, 17, 64, 128, 3, 2, 1), (5, 9, 9, 128, 128, 3, 1, 1),
                                                       (2, 17, 17, 64, 128, 1, 2, 0), (4, 3, 3, 512, 512, 3, 1, 1), (700, 9, 9, 128, 128, 3, 1, 1)])
 def test_bf16_convolutions_vs_rounded_operands(N, H, W, C, Co, KS, stride, pad, lib_options):
@@ -814,9 +827,9 @@ def test_bf16_gemm_variants(lib_options):
 def test_bf16_av_training_step_vs_fp32_oracle(lib_options):
     """BASELINE configs[4] arithmetic end to end on the AV model (WaveNet encoder + trunk + LSTM head): bf16 operands in
     every convolution / dense GEMM, fp32 BatchNorm statistics, LSTM cell, loss.  SURVEY 7's tolerance for this mode: about
-    2e-2 relative on the logits vs the fp32 oracle; gradients must point the same way: cosine > 0.9 on every big tensor
-    (measured: 0.96 on the stem weights, whose gradient has passed 20 bf16 convolutions and train-mode BatchNorm over
-    only 12 frames; > 0.99 on the head)."""
+    2e-2 relative on the logits vs the fp32 oracle; every big gradient tensor within a relative-L2 bound of the oracle's
+    (BF16_GRAD_REL: by where the tensor sits -- the stem's gradient has passed 20 bf16 convolutions and train-mode BatchNorm
+    over only 12 frames)."""
     from oracle import head, models
     from packages.models.AV_Net import DeepVAD_AV
     from packages.models.utils import batch_binary_cross_entropy
@@ -848,9 +861,15 @@ def test_bf16_av_training_step_vs_fp32_oracle(lib_options):
         g, r = p.grad.cpu().flatten().double(), sd[k].grad.flatten().double()
         assert torch.isfinite(g).all(), k
         if r.numel() >= 4096:
-            cos = float((g @ r) / (g.norm() * r.norm()).clamp_min(1e-30))
-            print("bf16 grad cosine %-40s %.4f" % (k, cos))
-            assert cos > 0.9, (k, cos)
+            rel = float((g - r).norm() / r.norm().clamp_min(1e-30))
+            # per-tensor relative-L2 bounds: the head sees one bf16 product per operand; a trunk gradient has passed up to 20
+            # bf16 convolutions and train-mode BatchNorm over 12 frames (bound by depth: the stem's is the loosest)
+            bound = BF16_GRAD_REL["head"] if k.startswith(("lstm", "vad")) else (BF16_GRAD_REL["encoder"] if k.startswith("wavenet") else BF16_GRAD_REL["trunk"])
+            msg = "bf16 grad relL2 %-40s %.3e (bound %.1e)" % (k, rel, bound)
+            print(msg)
+            with open(os.path.join(OUT, "parity.log"), "a") as f:
+                f.write(msg + "\n")
+            assert rel < bound, msg
 
 
 # ------------------------------------------------------------------------------------------ boundary: bare modules, losses
@@ -1174,11 +1193,12 @@ def test_full_size_c3_trunk_train_mode_backward(lib_options):
         _report_grad("C3 slice d/d%s" % k, p.grad, sd2["features." + k].grad, 2.0, _grad_bound(flips2, 2e-3))
 
 
-def test_full_size_c3_trunk_batch_split_and_scale():
-    """BASELINE configs[2] shape: 512 lip crops.  Eval-mode trunk: frames are independent (512 == 2 x 256 up to the
-    float-atomic order of split tiles) and the stem is linear before the first ReLU, so scaling every conv weight of
-    a BN-free path is not available -- instead check positive homogeneity of the ReLU network in eval mode with the
-    BN shifts zeroed: f(a*x) == a*f(x)."""
+def test_full_size_c3_trunk_batch_split_and_scale(lib_options):
+    """BASELINE configs[2] shape: 512 lip crops.  Eval-mode trunk: frames are independent, so 512 == 2 x 256.  Every
+    schedule is deterministic (split tiles are combined in a fixed order): under the whole-tile schedule a frame's sums do not
+    depend on the batch it sits in and the two runs agree BIT FOR BIT; under the production stream-K schedule the split
+    points move with the batch size, i.e. only the fp32 summation order inside a tile differs (1e-6 of the largest value).
+    Positive homogeneity of the ReLU network in eval mode with the BN shifts zero: f(a*x) == a*f(x), a a power of two: exact."""
     from packages.models.Video_Net import DeepVAD_video
     from avvad import nn as avnn
     torch.manual_seed(0)
@@ -1188,23 +1208,40 @@ def test_full_size_c3_trunk_batch_split_and_scale():
         full = avnn.trunk_forward(m.features, x, False)
         parts = torch.cat([avnn.trunk_forward(m.features, x[:256], False), avnn.trunk_forward(m.features, x[256:], False)])
         assert full.shape == (512, 512) and torch.isfinite(full).all()
-        assert _max_rel(full, parts) < 1e-5
+        print("C3 eval 512 vs 2x256, stream-K: max rel %.2e" % _max_rel(full, parts))
+        assert _max_rel(full, parts) < 1e-6
         # running_mean = 0, beta = 0 (fresh BatchNorm) -> the eval network is conv/scale/ReLU/max/mean only
         half = avnn.trunk_forward(m.features, 0.5 * x, False)
-        assert _max_rel(half, 0.5 * full) < 1e-5
+        assert torch.equal(half, 0.5 * full)
+        lib_options("no_streamk", 1)
+        full_w = avnn.trunk_forward(m.features, x, False)
+        parts_w = torch.cat([avnn.trunk_forward(m.features, x[:256], False), avnn.trunk_forward(m.features, x[256:], False)])
+        assert torch.equal(full_w, parts_w)
 
 
-def test_full_size_c4_dp_shard_gradient_sum():
-    """BASELINE configs[3]/[4] per-GPU shard (64 sequences x 16 frames, W0 encoder, 2xLSTM1024): the data-parallel
-    property on ONE GPU.  With BatchNorm in eval mode the summed-over-sequences loss makes
-    grad(full batch) == grad(shard 0) + grad(shard 1) -- exactly what the SUM all-reduce relies on."""
-    from packages.models.AV_Net import DeepVAD_AV
-    from packages.models.utils import batch_binary_cross_entropy
-    sys_path_bench = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def _load_bench():
     import importlib.util
-    spec = importlib.util.spec_from_file_location("bench", os.path.join(sys_path_bench, "bench.py"))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
+    return bench
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_full_size_c4_dp_shard_gradient_sum(dtype, lib_options):
+    """BASELINE configs[3]/[4] per-GPU shard (64 sequences x 16 frames, W0 encoder, 2xLSTM1024): the data-parallel
+    property on ONE GPU.  With BatchNorm in eval mode the summed-over-sequences loss makes
+    grad(full batch) == grad(shard 0) + grad(shard 1) -- exactly what the SUM all-reduce relies on.  Every schedule is
+    deterministic; what differs between the three runs is the fp32 summation order over samples (split points move with
+    the batch size) and, rarely, a ReLU unit whose pre-activation sits within rounding of zero.  f32: relative L2 <= 2e-4 per
+    tensor.  bf16 (BASELINE configs[4]'s arithmetic at its real shape): the same property holds -- the rounding of a
+    sample's activations does not depend on its batch -- with the bound widened to 2e-3 for bf16-rounded gradient operands."""
+    from packages.models.AV_Net import DeepVAD_AV
+    from packages.models.utils import batch_binary_cross_entropy
+    bench = _load_bench()
+    if dtype == "bf16":
+        lib_options("bf16", 1)
     torch.manual_seed(0)
     m = DeepVAD_AV(2, 1024, 1, wavenet_params=bench.W0).to(DEV).eval()
     wave, video, target, lengths = bench.make_inputs(torch, 64, 1234, torch.device(DEV))
@@ -1223,10 +1260,85 @@ def test_full_size_c4_dp_shard_gradient_sum():
     lf, gf = grads(slice(0, 64))
     l0, g0 = grads(slice(0, 32))
     l1, g1 = grads(slice(32, 64))
-    assert abs(lf - (l0 + l1)) < 1e-3 * abs(lf)
+    lf2, gf2 = grads(slice(0, 64))
+    assert lf == lf2 and all(torch.equal(a, b) for a, b in zip(gf, gf2))      # run to run: the same bits
+    assert abs(lf - (l0 + l1)) < (1e-5 if dtype == "f32" else 1e-3) * abs(lf)
     worst = max(float(((a + b) - f).norm() / f.norm().clamp_min(1e-30)) for f, a, b in zip(gf, g0, g1))
-    print("DP shard-sum property: loss %.4f = %.4f + %.4f, worst relL2 over %d tensors %.2e" % (lf, l0, l1, len(gf), worst))
-    assert worst < 5e-3       # float-atomic split-K order differs between the three runs; a wrong shard sum would be O(1)
+    print("DP shard-sum property (%s): loss %.4f = %.4f + %.4f, worst relL2 over %d tensors %.2e" % (dtype, lf, l0, l1, len(gf), worst))
+    assert worst < (2e-4 if dtype == "f32" else 2e-3)
+
+
+def test_bf16_benched_model_ragged_logits_vs_fp32_oracle(lib_options):
+    """BASELINE configs[4] at the BENCHED model (W0 encoder, ResNet-18, 2 x LSTM(1024), FC; sequences of the benchmark's
+    shape): logits of a ragged 4-sequence slice in train mode under option bf16 against the fp32 CPU oracle, within
+    SURVEY 7's bf16 tolerance 2e-2 * max|ref|; the same slice in fp32 within 1e-4 (the north-star bound) for contrast.
+    This is bench.py's parity probe (`cpu_ref_max_abs_delta`) as a test."""
+    from oracle import models
+    from packages.models.AV_Net import DeepVAD_AV
+    bench = _load_bench()
+    torch.manual_seed(0)
+    m = DeepVAD_AV(2, 1024, 1, wavenet_params=bench.W0)
+    wave, video, target, lengths = bench.make_inputs(torch, 4, 4321, None)
+    lens = [16, 9, 12, 5]
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    ref = models.av_net(sd, wave, video, lens, 2, training=True, wavenet_cfg=bench.W0)
+    m = m.to(DEV).train()
+    with torch.no_grad():
+        y32 = m(wave.to(DEV), video.to(DEV), torch.LongTensor(lens))
+    _report("benched model, fp32 ragged logits", y32, ref, 1e-4)
+    lib_options("bf16", 1)
+    m.load_state_dict(sd)                                    # (the fp32 pass moved the running statistics)
+    with torch.no_grad():
+        y16 = m(wave.to(DEV), video.to(DEV), torch.LongTensor(lens))
+    _report("benched model, bf16 ragged logits", y16, ref, 2e-2 * float(ref.abs().max()))
+    assert float((y16.cpu() - ref).abs().max()) > 1e-6      # the option really changed the arithmetic
+    for b, n in enumerate(lens):                             # padded steps: the Linear bias, exactly, in either arithmetic
+        assert torch.equal(y16[b, n:], y32[b, n:])
+
+
+def test_conv2d_refuses_kernels_beyond_the_tap_mask():
+    """The im2col gathers keep one validity bit per tap in a 32-bit word: a 7x7 kernel on >= 32 channels must be refused
+    (AVVAD_EINVAL), not computed with aliased taps."""
+    import ctypes as Ct
+    from avvad import _lib as L
+    lib = L.lib()
+    st = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(2, 17, 17, 32, 64, 7, 1, 3)
+    x = torch.zeros(2, 17, 17, 32, device=DEV); w = torch.zeros(49 * 32, 64, device=DEV); y = torch.zeros(2, 17, 17, 64, device=DEV)
+    assert lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(w), L.ptr(y), Ct.byref(d), None, 0, st) == -1
+    assert lib.avvad_conv2d_dgrad(L.ptr(y), L.ptr(w), L.ptr(x), Ct.byref(d), 0, None, 0, st) == -1
+    d5 = L.ConvDesc(2, 17, 17, 32, 64, 5, 1, 2)               # 25 taps fit
+    assert lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(w), L.ptr(y), Ct.byref(d5), None, 0, st) == 0
+
+
+def test_rccl_path_on_one_gpu(tmp_path):
+    """The RCCL code path executed on the one GPU there is: a fresh child process (torch.distributed.run, WORLD_SIZE=1,
+    backend nccl) trains the AV model with BucketReducer(force_hooks=True) -- ProcessGroupNCCL, hooks + in-place sinks,
+    async all_reduce on slices of the flat CUDA buffer, the side-stream ordering, the presence-bitmap collective -- and
+    without a reducer; at world size 1 the SUM is the identity, so the gradients must agree BIT FOR BIT."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    out = str(tmp_path / "rccl1.pt")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AVVAD_DIST_BACKEND", None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(os.path.dirname(os.path.abspath(__file__)), "rccl_one_gpu_worker.py"), out]
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    except subprocess.TimeoutExpired as e:
+        raise AssertionError("RCCL one-rank worker did not finish in 300 s:\n" + str(e.stderr or "")[-3000:])
+    assert r.returncode == 0 and os.path.exists(out), "RCCL one-rank worker failed (exit %d):\n%s" % (r.returncode, r.stderr[-3000:])
+    got = torch.load(out, weights_only=True)
+    print("RCCL world-1: %s, |grad| %.4e" % (got["info"], float(got["with"].norm())))
+    assert got["loss"][0] == got["loss"][1] and float(got["with"].norm()) > 0
+    assert torch.equal(got["with"], got["without"])
+    assert got["info"]["buckets"] > 2 and got["info"]["absent"] != []          # the unused `bn` pair was agreed absent ...
+    assert got["info"]["launched_from_hooks_last_step"] == got["info"]["buckets"]    # ... so every bucket left from the hooks
 
 
 @pytest.mark.parametrize("overlap", ["1", "0"])
