@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AVVAD_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libavvad_hip.so")
 
 TRUNK_NCONV = 20
-ABI_VERSION = 2          # include/avvad.h AVVAD_ABI_VERSION: the signatures below describe exactly this version
+ABI_VERSION = 3          # include/avvad.h AVVAD_ABI_VERSION: the signatures below describe exactly this version
 _ERR = {-1: "AVVAD_EINVAL (bad descriptor / unsupported shape)", -2: "AVVAD_EWORKSPACE (workspace too small)",
         -3: "AVVAD_ELAUNCH (kernel launch failed)"}
 
@@ -92,6 +92,10 @@ SIGNATURES = {
     "avvad_conv2d_fwd": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP, C.c_size_t, FP]),
     "avvad_conv2d_dgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), C.c_int, FP, C.c_size_t, FP]),
     "avvad_conv2d_wgrad": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP, C.c_size_t, FP]),
+    "avvad_conv2d_pack_weights_bf16": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP]),
+    "avvad_conv2d_fwd_bf16": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP, C.c_size_t, FP]),
+    "avvad_conv2d_dgrad_bf16": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), C.c_int, FP, C.c_size_t, FP]),
+    "avvad_conv2d_wgrad_bf16": (C.c_int, [FP, FP, FP, C.POINTER(ConvDesc), FP, C.c_size_t, FP]),
     "avvad_trunk_workspace": (C.c_size_t, [C.POINTER(TrunkDesc)]),
     "avvad_trunk_activation": (C.c_int, [C.POINTER(TrunkDesc), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_int),
                                          C.POINTER(C.c_int)]),

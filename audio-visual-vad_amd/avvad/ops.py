@@ -35,6 +35,31 @@ def side_streams():
     return list(_SIDE.values())
 
 
+_FORK = {}        # device -> the stream that forked work onto the side stream (DeepVAD_AV.forward's caller stream)
+
+
+def note_fork(main):
+    _FORK[torch.cuda.current_device()] = main
+
+
+def _join_side_after_backward():
+    """Called from a Function.backward that ran on the side stream and wrote parameter gradients IN PLACE.  autograd
+    joins the streams of a backward pass through its AccumulateGrad nodes; gradients written in place bypass those, so
+    the engine never learns that the side stream took part and the caller's stream would NOT wait for it when
+    backward() returns: an optimiser step (or a .cpu() of a gradient) could overtake the encoder's backward kernels.
+    (Observed: bimodal 1e-7 differences between identical trainings of a tiny model -- Adam read the encoder's gradients
+    before or after they were complete.)  The join is queued as an end-of-backward callback, so the trunk's backward on
+    the main stream is not made to wait in the middle of the pass."""
+    if not _SIDE:                 # no side stream was ever created (audio-only / video-only models, CPU-side unit tests)
+        return
+    dev = torch.cuda.current_device()
+    side = _SIDE.get(dev)
+    if side is None or torch.cuda.current_stream() != side:
+        return
+    main = _FORK.get(dev) or torch.cuda.default_stream()
+    torch.autograd.Variable._execution_engine.queue_callback(lambda: main.wait_stream(side))
+
+
 def overlap_enabled():
     return _OVERLAP
 
@@ -83,6 +108,8 @@ def _grad_target(p, needed):
 def _finish_grads(params, targets):
     """returned gradients for autograd (None where written in place) + sink notification"""
     out = []
+    if any(direct for _, direct in targets):
+        _join_side_after_backward()
     for p, (g, direct) in zip(params, targets):
         if direct:
             for sink in GRAD_SINKS:

@@ -41,7 +41,16 @@ class FlatAdam:
         self.lr, self.betas, self.eps = lr, betas, eps
         self.t = 0
 
+    def _join(self):
+        """Gradients may have been written on the side HIP stream (ops.side_stream()): order this stream behind it."""
+        from . import ops
+        cur = torch.cuda.current_stream()
+        for st in ops.side_streams():
+            if st != cur:
+                cur.wait_stream(st)
+
     def step(self):
+        self._join()
         self.t += 1
         L.check(L.lib().avvad_adam_step(L.ptr(self.flat), L.ptr(self.flat_grad), L.ptr(self.exp_avg),
                                         L.ptr(self.exp_avg_sq), self.flat.numel(), self.lr, self.betas[0],
@@ -49,6 +58,7 @@ class FlatAdam:
                                         C.c_void_p(torch.cuda.current_stream().cuda_stream)), "avvad_adam_step")
 
     def zero_grad(self):
+        self._join()
         self.flat_grad.zero_()
         for p, o in zip(self.params, self.offsets):       # re-attach if something replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_grad.data_ptr() + 4 * o:

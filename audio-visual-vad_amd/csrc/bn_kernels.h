@@ -174,6 +174,21 @@ __global__ void bn_bwd_finalize(const double* __restrict__ part, int nchunk, lon
 // ------------------------------------------------------------------ fused elementwise (16-byte accesses, C % 4 == 0)
 __device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return fmaf(x, sc, sh); }
 
+// Quads of bf16 (the trunk's bf16 data path, option "bf16"): activations that only convolutions consume are STORED as bf16
+// (round to nearest even: a plain cast, v_cvt_pk_bf16_f32 on gfx950 -- NaNs stay NaNs) by the elementwise kernel that
+// produces them; 8-byte accesses.
+typedef __bf16 bn_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float bn_f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_quad_bf16(void* base, long quad, const float (&o)[4]) {
+  const bn_f32x4 f = {o[0], o[1], o[2], o[3]};
+  reinterpret_cast<bn_bf16x4*>(base)[quad] = __builtin_convertvector(f, bn_bf16x4);
+}
+__device__ __forceinline__ float4 load_quad_bf16(const void* base, long quad) {
+  const bn_bf16x4 h = reinterpret_cast<const bn_bf16x4*>(base)[quad];
+  const bn_f32x4 f = __builtin_convertvector(h, bn_f32x4);
+  return make_float4(f[0], f[1], f[2], f[3]);
+}
+
 // The elementwise kernels run 256-thread blocks with a grid-stride loop: the stride (gridDim*256 quads) is a multiple
 // of C/4 whenever C/4 divides 256, so a thread's channel quad never changes and its per-channel coefficients are
 // loaded ONCE into registers -- per-iteration coefficient loads (up to 20 scalar loads per float4 of data) made these
@@ -181,6 +196,8 @@ __device__ __forceinline__ float bn_affine(float x, float sc, float sh) { return
 __device__ __forceinline__ float4 ld4(const float* p, int c) { return *reinterpret_cast<const float4*>(p + c); }
 
 // y = [relu]( x*scale+shift  [+ idn | + idn*iscale+ishift] )
+// OB: y is stored as bf16; IB: the identity input idn is bf16 (a block input of the bf16 data path; never with iscale)
+template <bool OB = false, bool IB = false>
 __global__ void __launch_bounds__(256)
     bn_act(const float* __restrict__ x, const float* __restrict__ scale, const float* __restrict__ shift,
            const float* __restrict__ idn, const float* __restrict__ iscale, const float* __restrict__ ishift,
@@ -199,14 +216,15 @@ __global__ void __launch_bounds__(256)
     const float4 v = reinterpret_cast<const float4*>(x)[i];
     float o[4] = {bn_affine(v.x, sc.x, sh.x), bn_affine(v.y, sc.y, sh.y), bn_affine(v.z, sc.z, sh.z), bn_affine(v.w, sc.w, sh.w)};
     if (idn) {
-      const float4 d = reinterpret_cast<const float4*>(idn)[i];
+      const float4 d = IB ? load_quad_bf16(idn, i) : reinterpret_cast<const float4*>(idn)[i];
       if (iscale) {
         o[0] += bn_affine(d.x, a.x, b.x); o[1] += bn_affine(d.y, a.y, b.y);
         o[2] += bn_affine(d.z, a.z, b.z); o[3] += bn_affine(d.w, a.w, b.w);
       } else { o[0] += d.x; o[1] += d.y; o[2] += d.z; o[3] += d.w; }
     }
     if (relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
-    reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if constexpr (OB) store_quad_bf16(y, i, o);
+    else reinterpret_cast<float4*>(y)[i] = make_float4(o[0], o[1], o[2], o[3]);
     // the ReLU mask of this quad as one byte (bit j: y[j] > 0): what the backward reads instead of y (1/16 of its bytes)
     if (qmask_out)
       qmask_out[i] = (unsigned char)((o[0] > 0.f ? 1 : 0) | (o[1] > 0.f ? 2 : 0) | (o[2] > 0.f ? 4 : 0) | (o[3] > 0.f ? 8 : 0));
@@ -215,6 +233,9 @@ __global__ void __launch_bounds__(256)
 
 // dx = k0*(g - k1 - xhat*k2), g = dy*(ymask>0);  optionally also writes g (identity branch of the residual)
 // (dx may alias dy: each element is read, then written, by the same thread)
+// OB: dx is stored as bf16 (the bf16 data path: dx only feeds the data- and weight-gradient convolutions; it must then NOT
+// alias dy)
+template <bool OB = false>
 __global__ void __launch_bounds__(256)
     bn_bwd_apply(const float* __restrict__ x, const float* dy, const float* __restrict__ ymask,
                  const float* __restrict__ mean, const float* __restrict__ invstd, const float* __restrict__ coef,
@@ -262,7 +283,8 @@ __global__ void __launch_bounds__(256)
       const float xh = (xs[j] - m4[j]) * i4[j];
       o[j] = a4[j] * (g[j] - b4[j] - xh * c4[j]);
     }
-    reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
+    if constexpr (OB) store_quad_bf16(dx, i, o);
+    else reinterpret_cast<float4*>(dx)[i] = make_float4(o[0], o[1], o[2], o[3]);
     if (gout) reinterpret_cast<float4*>(gout)[i] = make_float4(g[0], g[1], g[2], g[3]);
   }
 }

@@ -268,9 +268,10 @@ struct EpiWgrad {
   int cs;
   int Cch, T;
   unsigned mg_T;
+  int sh = 5;         // log2 of the channel chunk: 5 (fp32 engine, 32-channel chunks) or 6 (bf16 engine, 64)
   __device__ __forceinline__ float* ptr(int m, int n) const {
-    const int q = m >> 5, cc = fast_div(q, mg_T), tap = q - cc * T;
-    return C + (long)(tap * Cch + cc * 32 + (m & 31)) * ldc + n;
+    const int q = m >> sh, cc = fast_div(q, mg_T), tap = q - cc * T;
+    return C + (long)(tap * Cch + (cc << sh) + (m & ((1 << sh) - 1))) * ldc + n;
   }
 };
 

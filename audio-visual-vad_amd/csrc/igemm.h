@@ -42,8 +42,17 @@ struct EpiStore {
   const float* bias;  // per column n, may be null (added by the kernel: once per column, before the row loop)
   int mode;           // 0 store, 1 / 2 C += v
   int cs = 1;         // column stride (elements)
+  // Column statistics of the finished product (BatchNorm's batch statistics, fused): stat[(tm * 2 + 0) * N + n] = sum over the
+  // rows of M tile tm of C[m][n], [(tm * 2 + 1) * N + n] = sum of squares, as doubles; every (tm, n) is written exactly once
+  // per launch -- by the kernel for tiles it finishes itself, by fixup_tile for tiles cut along K.  Needs mode 0 / 1 on a
+  // row-major output with cs == 1, ldc % 4 == 0, N % 4 == 0 (checked by launch()).  null: no statistics.
+  double* stat = nullptr;
   __device__ __forceinline__ float* ptr(int m, int n) const { return C + (long)m * ldc + (long)n * cs; }
 };
+template <class Epi, class = void>
+struct HasStat : std::false_type {};
+template <class Epi>
+struct HasStat<Epi, std::void_t<decltype(Epi::stat)>> : std::true_type {};
 
 // ---------------------------------------------------------------- dense operands
 // element (x, k) = p[x*ld + k]
@@ -592,6 +601,42 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
           }
         }
       }
+    if constexpr (HasStat<Epi>::value) {
+      // Fused BatchNorm statistics (see EpiStore::stat): this worker finished the tile by itself, so the sums are final.
+      // Lane (li, lh) holds column n of its wave's TN column blocks and rows (r, lh) of TM x 16 registers: 16 * TM terms in
+      // fp32, then doubles -- across the lane halves by a cross-lane move, across the WGM row waves through LDS (free: every
+      // wave is past the K loop's last barrier), in a fixed order.  Rows beyond M hold exact zeros (their operand rows were
+      // out of range) and add nothing.
+      if (E.stat != nullptr && kt0 == 0 && kt1 == ktiles) {
+        double* red = reinterpret_cast<double*>(smem);          // [WGM][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float sf = 0.f, qf = 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sf += v; qf = fmaf(v, v, qf); }
+          double sd = (double)sf, qd = (double)qf;
+          sd += __shfl_xor(sd, 32, 64);
+          qd += __shfl_xor(qd, 32, 64);
+          if (lh_e == 0) {
+            const int cl = wn * (BN / WGN) + j * 32 + li_e;
+            red[(wm * BN + cl) * 2 + 0] = sd;
+            red[(wm * BN + cl) * 2 + 1] = qd;
+          }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < N) {
+          double a = 0, b = 0;
+#pragma unroll
+          for (int w = 0; w < WGM; ++w) { a += red[(w * BN + t) * 2 + 0]; b += red[(w * BN + t) * 2 + 1]; }
+          const long tm = tile / ntn;
+          E.stat[(tm * 2 + 0) * N + n0 + t] = a;
+          E.stat[(tm * 2 + 1) * N + n0 + t] = b;
+        }
+        // (no barrier behind the reads: the next segment's prologue has one in front of its first LDS write)
+      }
+    }
 #ifdef AVVAD_PROF
     const unsigned long long tp3 = PROF_T();
     PROF_ADD(0, 1); PROF_ADD(1, tp1 - tp0); PROF_ADD(2, tp2 - tp1); PROF_ADD(3, tbar); PROF_ADD(4, tstage); PROF_ADD(5, tp3 - tp2);
@@ -745,6 +790,80 @@ __global__ void __launch_bounds__(256)
     if (n0 + e < N) *E.ptr(m, n0 + e) += sv[e];
 }
 
+// Fix-up of split tiles WITH the fused column statistics (EpiStore::stat): one workgroup per remainder tile.  Thread
+// (cq, rg) owns the float4 column cq of rows rg, rg + RG, ...: it adds the tile's slabs in ascending worker order onto the
+// piece the first worker stored, writes the total back and keeps sum / sum of squares of its columns (fp32 over its BM / RG
+// rows, then doubles); the RG row groups meet in LDS in a fixed order.  Tiles that one worker finished by itself are skipped
+// (the kernel wrote their statistics).
+template <int BM, int BN>
+__global__ void __launch_bounds__(256)
+    fixup_tile(const EpiStore E, const float* __restrict__ slab, const int M, const int N, const int ktiles, const long G,
+               const int full_rounds, const int rem_tiles, const int ntn) {
+  constexpr int CQ = BN / 4, RG = 256 / CQ, RPT = BM / RG;
+  static_assert(RPT % 4 == 0, "four rows in flight per thread");
+  __shared__ double red[RG * BN * 2];
+  const int tr = blockIdx.x;
+  const unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, Gu = (unsigned)G;
+  const unsigned it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  const int ga = (int)(((it0 + 1u) * Gu + R - 1u) / R) - 1, gb = (int)(((it1 + 1u) * Gu + R - 1u) / R) - 1;
+  if (gb <= ga) return;                                  // block-uniform
+  const bool sparse = R < Gu;
+  const unsigned tile = (unsigned)full_rounds * Gu + (unsigned)tr;
+  const int tm = (int)(tile / (unsigned)ntn);
+  const int m0 = tm * BM, n0 = (int)(tile % (unsigned)ntn) * BN;
+  const int cq = threadIdx.x % CQ, rg = threadIdx.x / CQ;
+  const int n = n0 + cq * 4;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+  if (n < N) {                                           // (N % 4 == 0: a float4 column is inside or outside as a whole)
+#pragma unroll 1
+    for (int rr = 0; rr < RPT; rr += 4) {
+      float4 tot[4];
+      bool live[4];
+      const float* sp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int row = rg + RG * (rr + u);
+        live[u] = m0 + row < M;
+        sp[u] = slab + (long)(live[u] ? row : 0) * BN + cq * 4;
+        tot[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      for (int g = ga + 1; g <= gb; ++g) {
+        if (sparse && !(((unsigned)(g + 1) * R) / Gu > ((unsigned)g * R) / Gu)) continue;     // this worker's share was empty
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(sp[u] + (long)g * (BM * BN));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { tot[u].x += v[u].x; tot[u].y += v[u].y; tot[u].z += v[u].z; tot[u].w += v[u].w; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (!live[u]) continue;
+        float4* const cp = reinterpret_cast<float4*>(E.C + (long)(m0 + rg + RG * (rr + u)) * E.ldc + n);
+        float4 o = *cp;
+        o.x += tot[u].x; o.y += tot[u].y; o.z += tot[u].z; o.w += tot[u].w;
+        *cp = o;
+        s4[0] += o.x; s4[1] += o.y; s4[2] += o.z; s4[3] += o.w;
+        q4[0] = fmaf(o.x, o.x, q4[0]); q4[1] = fmaf(o.y, o.y, q4[1]); q4[2] = fmaf(o.z, o.z, q4[2]); q4[3] = fmaf(o.w, o.w, q4[3]);
+      }
+    }
+  }
+  if (E.stat == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    red[(rg * BN + cq * 4 + e) * 2 + 0] = (double)s4[e];
+    red[(rg * BN + cq * 4 + e) * 2 + 1] = (double)q4[e];
+  }
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (c < BN && n0 + c < N) {
+    double a = 0, b = 0;
+#pragma unroll 4
+    for (int w = 0; w < RG; ++w) { a += red[(w * BN + c) * 2 + 0]; b += red[(w * BN + c) * 2 + 1]; }
+    E.stat[((long)tm * 2 + 0) * N + n0 + c] = a;
+    E.stat[((long)tm * 2 + 1) * N + n0 + c] = b;
+  }
+}
+
 constexpr int NUM_CU = 256;  // MI355X
 
 // Floats of slab workspace a launch may need: one BM x BN tile per persistent worker (512 x 128x128 = 1024 x 128x64 =
@@ -811,6 +930,11 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e_in, int M, int
   }
   const int fr = (int)full_rounds, rt = (int)rem;
   const bool bf = allow_bf16 && tn.bf16;
+  bool stat = false;
+  if constexpr (std::is_same<Epi, EpiStore>::value) {
+    stat = e.stat != nullptr;
+    if (stat && (e.cs != 1 || (e.ldc & 3) || (N & 3) || (((uintptr_t)e.C) & 15) || kchunks > 0 || e.bias != nullptr)) return AVVAD_EINVAL;
+  }
   if constexpr (HasFinish<Epi>::value) {
     // finish4() runs in the fix-up kernel: only when every tile of the product goes through the stream-K pool
     e.active = (rt > 0 && kchunks == 0 && fr == 0 && (long)rt == ntiles) ? 1 : 0;
@@ -835,7 +959,10 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e_in, int M, int
     else AVVAD_IGEMM_LAUNCH(true, (BIG ? 512 : 256));
   }
 #undef AVVAD_IGEMM_LAUNCH
-  if (rt > 0 && kchunks == 0) {
+  if (rt > 0 && kchunks == 0 && stat) {
+    if constexpr (std::is_same<Epi, EpiStore>::value)
+      hipLaunchKernelGGL((fixup_tile<BM, BN>), dim3(rt), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));
+  } else if (rt > 0 && kchunks == 0) {
     const int deep = tn.no_fixup1 > 1 ? tn.no_fixup1 : 6;     // (option values > 1: the depth threshold, tuning aid)
     if ((G + rt - 1) / rt <= deep && tn.no_fixup1 != 1)      // a handful of slabs per tile: one wave per strip
       hipLaunchKernelGGL((fixup1<BM, BN, Epi>), dim3(rt * (BM * BN / 1024)), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));

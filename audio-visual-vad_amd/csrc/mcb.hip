@@ -207,7 +207,7 @@ extern "C" int avvad_mcb_fusion_fwd(const float* audio, const float* video, cons
                        (const float*)nullptr, (const float*)nullptr, (long)d->rows, d->D, c.per, w.part);
   hipLaunchKernelGGL(bn_finalize, dim3(cdiv(d->D, FIN_CH)), dim3(256), 0, s, w.part, c.n, (long)d->rows, d->D, bn_w, bn_b, bn_rm,
                      bn_rv, d->training, d->momentum, d->eps, w.scale, w.shift, w.mean, w.invstd);
-  hipLaunchKernelGGL(bn_act, dim3(ew_grid(n / 4)), dim3(256), 0, s, w.Y2, w.scale, w.shift, (const float*)nullptr,
+  hipLaunchKernelGGL((bn_act<false, false>), dim3(ew_grid(n / 4)), dim3(256), 0, s, w.Y2, w.scale, w.shift, (const float*)nullptr,
                      (const float*)nullptr, (const float*)nullptr, out, n / 4, d->D, 0);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
@@ -228,7 +228,7 @@ extern "C" int avvad_mcb_fusion_bwd(const float* audio, const float* video, cons
                      (long)d->rows, d->D, c.per, w.part);
   hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(d->D, FIN_CH)), dim3(256), 0, s, w.part, c.n, (long)d->rows, d->D, bn_w, w.invstd,
                      d->training, dbn_w, dbn_b, w.coef);
-  hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid(n / 4)), dim3(256), 0, s, w.Y2, dout, (const float*)nullptr, w.mean, w.invstd,
+  hipLaunchKernelGGL((bn_bwd_apply<false>), dim3(ew_grid(n / 4)), dim3(256), 0, s, w.Y2, dout, (const float*)nullptr, w.mean, w.invstd,
                      w.coef, w.G, (float*)nullptr, n / 4, d->D);
   hipLaunchKernelGGL(ssqrt_bwd, dim3(ew_grid(n)), dim3(256), 0, s, w.Y, w.sumsq, w.G, n, d->eps);
   if (daudio || dvideo)

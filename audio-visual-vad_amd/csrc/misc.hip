@@ -26,6 +26,7 @@ const OptName kOpts[] = {
     {"wn_grid", "AVVAD_WN_GRID", &AvvadTune::wn_grid},
     {"wn_dx", "AVVAD_WN_DX", &AvvadTune::wn_dx},
     {"bf16", "AVVAD_BF16", &AvvadTune::bf16},
+    {"no_fused_stats", "AVVAD_NO_FUSED_STATS", &AvvadTune::no_fused_stats},
     {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
 };
 int parse_opt(const char* name, const char* v) {

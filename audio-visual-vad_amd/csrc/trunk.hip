@@ -15,7 +15,7 @@
 // implicit GEMM of igemm.h; BatchNorm statistics are a two-stage column
 // reduction in fp64; normalisation / ReLU / residual add / pooling are fused
 // elementwise kernels with 16-byte accesses.
-#include "conv_ops.h"
+#include "bgemm.h"
 
 using convop::Geom;
 
@@ -39,6 +39,7 @@ struct Plan {
   Geom geom[NCONV];
   // workspace offsets in floats
   size_t wf[NCONV], wd[NCONV];
+  size_t wf16[NCONV], wd16[NCONV];   // bf16 packs of the bf16 data path: [co][(cc,tap,r)] and [c][(cc,tap,r)] (64-channel chunks cc)
   size_t bn_scale, bn_shift, bn_mean, bn_invstd;  // [NCONV][MAXC]
   size_t coef;                                    // [3][MAXC] backward coefficients
   size_t part;                                    // doubles: [STAT_CHUNKS][2][MAXC]
@@ -88,6 +89,8 @@ static void make_plan(const avvad_trunk_desc* d, Plan* p) {
     const size_t n = (size_t)c.ks * c.ks * c.cin * c.cout;
     p->wf[i] = take(n);
     p->wd[i] = (i == 0) ? 0 : take(n);
+    p->wf16[i] = (i == 0) ? 0 : take(n / 2);
+    p->wd16[i] = (i == 0) ? 0 : take(n / 2);
   }
   p->bn_scale = take(NCONV * MAXC); p->bn_shift = take(NCONV * MAXC);
   p->bn_mean = take(NCONV * MAXC); p->bn_invstd = take(NCONV * MAXC);
@@ -136,6 +139,8 @@ struct PackTab {
   const float* w[NCONV];
   float* wf[NCONV];
   float* wd[NCONV];      // may be null
+  __bf16* wf16[NCONV];   // bf16 data path (may be null): wf16[co][(cc * T + tap) * 64 + r] = w[co][cc * 64 + r][tap]
+  __bf16* wd16[NCONV];   //                               wd16[c][(cc * T + tap) * 64 + r] = w[cc * 64 + r][c][tap]
   int cout[NCONV], cin[NCONV], ks[NCONV];
   int blk0[NCONV + 1];   // first block of conv i (conv 0 = stem: its 3 input channels are folded, see pack_stem)
 };
@@ -165,6 +170,16 @@ __global__ void __launch_bounds__(256) pack_all(const PackTab tab) {
   }
   __syncthreads();
   float* wd = tab.wd[i];
+  __bf16* wf16 = tab.wf16[i];
+  __bf16* wd16 = tab.wd16[i];
+  if (wf16) {     // the bf16 data path takes only these (K-contiguous rows in the GEMM's own K order; C, Co multiples of 64)
+    for (int idx = threadIdx.x; idx < T * 1024; idx += 256) {
+      const int tap = idx >> 10, a = (idx >> 5) & 31, b = idx & 31;
+      wf16[(long)(co0 + a) * (T * C) + ((c0 >> 6) * T + tap) * 64 + (c0 & 63) + b] = (__bf16)tl[a * PACK_LD + b * T + tap];
+      if (wd16) wd16[(long)(c0 + a) * (T * Co) + ((co0 >> 6) * T + tap) * 64 + (co0 & 63) + b] = (__bf16)tl[b * PACK_LD + a * T + tap];
+    }
+    return;
+  }
   for (int idx = threadIdx.x; idx < T * 1024; idx += 256) {
     const int tap = idx >> 10, a = (idx >> 5) & 31, b = idx & 31;
     wf[((long)(tap * C + c0 + a)) * Co + co0 + b] = tl[b * PACK_LD + a * T + tap];           // row (tap, c = a), column co = b
@@ -283,6 +298,7 @@ __global__ void __launch_bounds__(256)
 // stem: p0 = maxpool3x3/2 pad1 ( relu(bn(c0)) ).  Also records, per pooled element, WHICH window position (dh*3+dw) holds
 // the maximum -- the first one in row-major scan order, torch's rule (max_pool2d updates on a strict '>') -- so that the
 // backward sends the gradient to exactly that element even when flat image regions produce exact ties.
+template <bool OB = false>     // OB: p0 is stored as bf16 (the bf16 data path)
 __global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
                                   float* __restrict__ p0, unsigned* __restrict__ am, int N, int Hc, int Wc, int Hp, int Wp) {
   const long total = (long)N * Hp * Wp * 16;  // 64 channels = 16 quads
@@ -308,7 +324,8 @@ __global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __r
           if (y[k] > m[k]) { m[k] = y[k]; idx[k] = (unsigned)(dh * 3 + dw); }
       }
     }
-    reinterpret_cast<float4*>(p0)[i] = make_float4(m[0], m[1], m[2], m[3]);
+    if constexpr (OB) store_quad_bf16(p0, i, m);
+    else reinterpret_cast<float4*>(p0)[i] = make_float4(m[0], m[1], m[2], m[3]);
     if (am) am[i] = idx[0] | (idx[1] << 8) | (idx[2] << 16) | (idx[3] << 24);
   }
 }
@@ -349,12 +366,13 @@ __global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __
 }
 
 // feat[n][c] = mean over HW of y[n][hw][c]
+template <bool IB = false>     // IB: y is bf16 (the bf16 data path)
 __global__ void avgpool_fwd(const float* __restrict__ y, float* __restrict__ feat, int N, int HW, int C) {
   const long total = (long)N * C;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int c = (int)(i % C); const long n = i / C;
     float s = 0.f;
-    for (int p = 0; p < HW; ++p) s += y[(n * HW + p) * C + c];
+    for (int p = 0; p < HW; ++p) s += IB ? (float)reinterpret_cast<const __bf16*>(y)[(n * HW + p) * C + c] : y[(n * HW + p) * C + c];
     feat[i] = s / (float)HW;
   }
 }
@@ -470,10 +488,18 @@ static inline bool fits_u30(long n) { return n >= 0 && n < (1L << 30); }
 static inline bool taps_fit(const Geom& g) { return g.KS * g.KS <= 32; }
 // operands below 2 GiB take the buffer-addressed gathers (conv_ops.h "BUF")
 static inline bool fits_buf(long n_floats) { return n_floats >= 0 && n_floats < (1L << 29) - 64; }
+// rows per M tile of the forward GEMM of convolution g (what the fused BatchNorm statistics are laid out by), 0: the stem
+static inline int fwd_tile_rows(const Geom& g) {
+  if (g.C == 1) return 0;
+  if (avvad_tune().bf16 == 1) return 128;                   // the bf16 engine's tiles (bgemm.h)
+  return g.Co <= 64 && !avvad_tune().no_tall ? 256 : 128;
+}
+// stat: per-M-tile column sums / sums of squares of y (igemm::EpiStore::stat), or null
 template <bool BUF>
-static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab) {
+static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
   const int M = g.N * g.Ho * g.Wo, K = g.KS * g.KS * g.C;
   igemm::EpiStore e{y, g.Co, nullptr, 0};
+  e.stat = g.C == 1 ? nullptr : stat;
   if (g.C == 1) {
     const int LDW = (g.W + 6) | 1;
     const size_t lds = (size_t)(g.H + 6) * LDW * sizeof(float);
@@ -494,9 +520,9 @@ static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, 
   if (g.Co <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s, slab) : igemm::launch<256, 64>(a, b, e, M, g.Co, K, 1, s, slab);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s, slab);
 }
-static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab) {
+static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat = nullptr) {
   const bool buf = fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.KS * g.KS * g.C * g.Co) && !avvad_tune().no_buf;
-  return buf ? conv_fwd_t<true>(x, wf, y, g, s, slab) : conv_fwd_t<false>(x, wf, y, g, s, slab);
+  return buf ? conv_fwd_t<true>(x, wf, y, g, s, slab, stat) : conv_fwd_t<false>(x, wf, y, g, s, slab, stat);
 }
 // dx (+)= dgrad
 template <bool BUF>
@@ -583,6 +609,79 @@ static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g,
   return buf ? conv_wgrad_t<true>(x, dy, pk, g, s, slab) : conv_wgrad_t<false>(x, dy, pk, g, s, slab);
 }
 
+// ------------------------------------------------------------------ the bf16 data path (option "bf16" = 1; bgemm.h)
+// Operands are bf16 in HBM: activations / output gradients NHWC bf16 (written by the BatchNorm elementwise kernels), weights
+// in the K-contiguous bf16 packs of pack_all.  Outputs are fp32 (raw convolution sums feed BatchNorm statistics; gradients
+// accumulate).  Channel counts must be multiples of 64 (every trunk convolution behind the stem), operands < 2 GiB.
+static inline bool native_bf16() { return avvad_tune().bf16 == 1; }
+static inline bool bf16_conv_ok(const Geom& g) {
+  return g.C % 64 == 0 && g.Co % 64 == 0 && taps_fit(g) && fits_buf((long)g.N * g.H * g.W * g.C / 2) &&
+         fits_buf((long)g.N * g.Ho * g.Wo * g.Co / 2) && fits_buf((long)g.KS * g.KS * g.C * g.Co / 2);
+}
+static int conv_fwd16(const float* x16, const float* wf16, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
+  if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
+  const int M = g.N * g.Ho * g.Wo, T = g.KS * g.KS, Kp = T * g.C / 2;
+  Geom gp = g;
+  gp.C = g.C / 2;                                            // the gather addresses bf16 PAIRS
+  convop::Im2colFwd<true> a{x16, gp, M, convop::tap_div(T, g.KS)};
+  bgemm::RowPairs b{wf16, Kp, g.Co, Kp};
+  igemm::EpiStore e{y, g.Co, nullptr, 0};
+  e.stat = stat;
+  if (g.Co <= 64) return bgemm::launch<128, 64, false>(a, b, e, M, g.Co, Kp, s, slab);
+  return bgemm::launch<128, 128, false>(a, b, e, M, g.Co, Kp, s, slab);
+}
+static int conv_dgrad16(const float* dy16, const float* wd16, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
+  if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
+  const int M = g.N * g.H * g.W, T = g.KS * g.KS, Kp = T * g.Co / 2;
+  Geom gp = g;
+  gp.Co = g.Co / 2;
+  if (g.stride == 2) {
+    if (!accumulate) hipLaunchKernelGGL(zero_f32, dim3(ew_grid((long)M * g.C)), dim3(256), 0, s, dx, (long)M * g.C);
+    for (int ph = 0; ph < 2; ++ph)
+      for (int pw = 0; pw < 2; ++pw) {
+        convop::S2Class c;
+        c.ph = ph; c.pw = pw;
+        c.Hc = (g.H - ph + 1) / 2; c.Wc = (g.W - pw + 1) / 2;
+        c.kh0 = (ph + g.pad) & 1; c.kw0 = (pw + g.pad) & 1;
+        c.nkh = c.kh0 < g.KS ? (g.KS - c.kh0 + 1) / 2 : 0;
+        c.nkw = c.kw0 < g.KS ? (g.KS - c.kw0 + 1) / 2 : 0;
+        c.oh = (ph + g.pad - c.kh0) / 2; c.ow = (pw + g.pad - c.kw0) / 2;
+        const int Mc = g.N * c.Hc * c.Wc, ntap = c.nkh * c.nkw;
+        if (Mc <= 0 || ntap <= 0) continue;
+        if (ntap > 4) return AVVAD_EINVAL;
+        c.mg_ntap = convop::div_magic(ntap); c.mg_nkw = convop::div_magic(c.nkw);
+        convop::Im2colDgradS2<true> a{dy16, gp, c, Mc};
+        bgemm::RowPairsSeg b{wd16, Kp, g.C, ntap * g.Co / 2, T, ntap, {0, 0, 0, 0}, convop::div_magic(ntap)};
+        for (int ia = 0; ia < c.nkh; ++ia)
+          for (int ib = 0; ib < c.nkw; ++ib) b.tap[ia * c.nkw + ib] = (c.kh0 + 2 * ia) * g.KS + (c.kw0 + 2 * ib);
+        convop::EpiS2 e{dx, g.C, nullptr, 1, 1, g.H, g.W, c.Hc, c.Wc, ph, pw, convop::div_magic(c.Hc * c.Wc), convop::div_magic(c.Wc)};
+        if ((unsigned long)(Mc + 128) * (unsigned long)(c.Hc * c.Wc) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
+        int rc;
+        if (g.C <= 64) rc = bgemm::launch<128, 64, false>(a, b, e, Mc, g.C, ntap * g.Co / 2, s, slab);
+        else rc = bgemm::launch<128, 128, false>(a, b, e, Mc, g.C, ntap * g.Co / 2, s, slab);
+        if (rc) return rc;
+      }
+    return AVVAD_OK;
+  }
+  convop::Im2colDgrad<true> a{dy16, gp, M, convop::tap_div(T, g.KS)};
+  bgemm::RowPairs b{wd16, Kp, g.C, Kp};
+  igemm::EpiStore e{dx, g.C, nullptr, accumulate ? 1 : 0};
+  if (g.C <= 64) return bgemm::launch<128, 64, false>(a, b, e, M, g.C, Kp, s, slab);
+  return bgemm::launch<128, 128, false>(a, b, e, M, g.C, Kp, s, slab);
+}
+static int conv_wgrad16(const float* x16, const float* dy16, float* pk, const Geom& g, hipStream_t s, float* slab) {
+  if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
+  const int T = g.KS * g.KS, M = T * g.C, K = g.N * g.Ho * g.Wo;
+  if ((unsigned long)(K + bgemm::BKU) * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
+  Geom gp = g;
+  gp.C = g.C / 2;
+  convop::WgradX<true> a{x16, gp, M / 2, K, convop::div_magic(g.Ho * g.Wo), convop::div_magic(g.Wo)};
+  igemm::ColPlain<4, true> b{dy16, g.Co / 2, g.Co / 2, K, 0};
+  convop::EpiWgrad e{pk, g.Co, nullptr, 0, 1, g.C, T, convop::div_magic(T), 6};
+  if (g.Co <= 64) return bgemm::launch<128, 64, true>(a, b, e, M, g.Co, K, s, slab);
+  return bgemm::launch<128, 128, true>(a, b, e, M, g.Co, K, s, slab);
+}
+
 struct StatCtx { double* part; int nchunk; long rows_per_chunk; };
 static StatCtx stat_ctx(Plan* p, float* ws, long M, int C) {
   StatCtx c;
@@ -598,11 +697,21 @@ static StatCtx stat_ctx(Plan* p, float* ws, long M, int C) {
 }
 
 // batch statistics of conv output i -> scale/shift/mean/invstd slots i (+ running stats)
+// where conv i's forward can leave its fused statistics (null: take the separate column-reduction pass)
+static double* fused_stat(Plan* p, float* ws, int i, const avvad_trunk_desc* d) {
+  const int rows = fwd_tile_rows(p->geom[i]);
+  if (!d->training || rows == 0 || avvad_tune().no_fused_stats) return nullptr;
+  const long M = (long)p->geom[i].N * p->geom[i].Ho * p->geom[i].Wo;
+  if ((long)cdiv(M, rows) * p->conv[i].cout > (long)STAT_CHUNKS * MAXC) return nullptr;      // the partial-sum buffer's size
+  return reinterpret_cast<double*>(ws + p->part);
+}
 static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, const avvad_trunk_params* prm,
                       const avvad_trunk_desc* d, hipStream_t s) {
   const int C = p->conv[i].cout;
   StatCtx sc = stat_ctx(p, ws, M, C);
-  if (d->training) {
+  if (fused_stat(p, ws, i, d)) {
+    sc.nchunk = cdiv(M, fwd_tile_rows(p->geom[i]));     // written by the convolution's epilogue / fix-up, one chunk per M tile
+  } else if (d->training) {
     hipLaunchKernelGGL(col_reduce<0>, dim3(sc.nchunk), dim3(256), 0, s, craw, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, M, C, sc.rows_per_chunk, sc.part);
   }
@@ -618,7 +727,10 @@ static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, cons
 // with the forward's saved scale / shift instead of reading the activation (ymask is then ignored)
 static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float* dy, const float* ymask, float* dx,
                        float* gout, long M, const avvad_trunk_params* prm, const avvad_trunk_grads* g,
-                       const avvad_trunk_desc* d, hipStream_t s, bool own_relu = false, const unsigned char* qmask = nullptr) {
+                       const avvad_trunk_desc* d, hipStream_t s, bool own_relu = false, const unsigned char* qmask = nullptr,
+                       bool out16 = false) {
+  // out16 (the bf16 data path): dx is stored as bf16, and the block output's ReLU mask comes from the byte mask in BOTH
+  // passes (the activation itself is bf16 there)
   const int C = p->conv[i].cout;
   StatCtx sc = stat_ctx(p, ws, M, C);
   const float* mean = ws + p->bn_mean + i * MAXC;
@@ -628,13 +740,18 @@ static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float
   // qmask: the block output's ReLU mask as one byte per quad, written by bn_act.  The apply kernel reads it instead of the
   // activation (32.5 -> 28.2 us); the column reduction keeps the float activation -- with byte loads it got 9 % SLOWER.
   if (own_relu) ymask = nullptr;
-  hipLaunchKernelGGL(col_reduce<1>, dim3(sc.nchunk), dim3(256), 0, s, xraw, dy, ymask, mean, invstd, M, C,
-                     sc.rows_per_chunk, sc.part, msc, msh);
+  const bool qred = out16 && qmask != nullptr;
+  hipLaunchKernelGGL(col_reduce<1>, dim3(sc.nchunk), dim3(256), 0, s, xraw, dy, qred ? (const float*)nullptr : ymask, mean, invstd, M, C,
+                     sc.rows_per_chunk, sc.part, msc, msh, qred ? qmask : (const unsigned char*)nullptr);
   hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, FIN_CH)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], invstd,
                      d->training, g->bn_w[i], g->bn_b[i], ws + p->coef);
   const long nq = M * C / 4;
-  hipLaunchKernelGGL(bn_bwd_apply, dim3(ew_grid(nq)), dim3(256), 0, s, xraw, dy, qmask ? (const float*)nullptr : ymask, mean, invstd,
-                     ws + p->coef, dx, gout, nq, C, msc, msh, qmask);
+  if (out16)
+    hipLaunchKernelGGL(bn_bwd_apply<true>, dim3(ew_grid(nq)), dim3(256), 0, s, xraw, dy, qmask ? (const float*)nullptr : ymask, mean, invstd,
+                       ws + p->coef, dx, gout, nq, C, msc, msh, qmask);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply<false>, dim3(ew_grid(nq)), dim3(256), 0, s, xraw, dy, qmask ? (const float*)nullptr : ymask, mean, invstd,
+                       ws + p->coef, dx, gout, nq, C, msc, msh, qmask);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }
@@ -705,6 +822,52 @@ extern "C" int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_pac
   return conv_wgrad(x, dy, dw_packed, g, (hipStream_t)s, slab_of(ws, ws_bytes));
 }
 
+// ---- the bf16 data path's convolutions on their own (bgemm.h): operands bf16 in HBM, fp32 results.  Exported for the
+// parity tests and bench.py's bf16 roofline probe; the trunk calls the same launchers when option "bf16" is 1.
+namespace {
+__global__ void pack_weights_bf16(const float* __restrict__ w, __bf16* __restrict__ wf16, __bf16* __restrict__ wd16, int Co, int C, int KS) {
+  const int T = KS * KS, n = Co * C * T;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    int r = i;                                                 // i indexes OIHW
+    const int tap = r % T; r /= T;
+    const int c = r % C; const int co = r / C;
+    const __bf16 v = (__bf16)w[i];
+    wf16[(long)co * (T * C) + ((c >> 6) * T + tap) * 64 + (c & 63)] = v;
+    if (wd16) wd16[(long)c * (T * Co) + ((co >> 6) * T + tap) * 64 + (co & 63)] = v;
+  }
+}
+}  // namespace
+extern "C" int avvad_conv2d_pack_weights_bf16(const float* w_oihw, void* wf16, void* wd16, const avvad_conv_desc* d, avvad_stream_t s) {
+  AVVAD_ENTER();
+  Geom g;
+  if (!w_oihw || !wf16 || !conv_geom(d, &g) || g.C % 64 || g.Co % 64) return AVVAD_EINVAL;
+  hipLaunchKernelGGL(pack_weights_bf16, dim3(ew_grid((long)g.Co * g.C * g.KS * g.KS)), dim3(256), 0, (hipStream_t)s, w_oihw,
+                     (__bf16*)wf16, (__bf16*)wd16, g.Co, g.C, g.KS);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+extern "C" int avvad_conv2d_fwd_bf16(const void* x16, const void* wf16, float* y, const avvad_conv_desc* d, void* ws, size_t ws_bytes,
+                                     avvad_stream_t s) {
+  AVVAD_ENTER();
+  Geom g;
+  if (!x16 || !wf16 || !y || !conv_geom(d, &g)) return AVVAD_EINVAL;
+  return conv_fwd16((const float*)x16, (const float*)wf16, y, g, (hipStream_t)s, slab_of(ws, ws_bytes), nullptr);
+}
+extern "C" int avvad_conv2d_dgrad_bf16(const void* dy16, const void* wd16, float* dx, const avvad_conv_desc* d, int accumulate,
+                                       void* ws, size_t ws_bytes, avvad_stream_t s) {
+  AVVAD_ENTER();
+  Geom g;
+  if (!dy16 || !wd16 || !dx || !conv_geom(d, &g)) return AVVAD_EINVAL;
+  return conv_dgrad16((const float*)dy16, (const float*)wd16, dx, g, accumulate, (hipStream_t)s, slab_of(ws, ws_bytes));
+}
+extern "C" int avvad_conv2d_wgrad_bf16(const void* x16, const void* dy16, float* dw_packed, const avvad_conv_desc* d, void* ws,
+                                       size_t ws_bytes, avvad_stream_t s) {
+  AVVAD_ENTER();
+  Geom g;
+  if (!x16 || !dy16 || !dw_packed || !conv_geom(d, &g)) return AVVAD_EINVAL;
+  return conv_wgrad16((const float*)x16, (const float*)dy16, dw_packed, g, (hipStream_t)s, slab_of(ws, ws_bytes));
+}
+
 extern "C" size_t avvad_trunk_workspace(const avvad_trunk_desc* d) {
   if (!d || d->N <= 0 || d->H < 32 || d->W < 32) return 0;
   Plan p;
@@ -737,6 +900,7 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
   if (ws_bytes < p.total * sizeof(float)) return AVVAD_EWORKSPACE;
   float* ws = (float*)wsv;
   int rc;
+  const bool b16 = native_bf16();        // the bf16 data path: activations between convolutions are stored as bf16
   // weights: OIHW -> packed
   {
     PackTab tab;
@@ -746,6 +910,8 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
       tab.w[i] = prm->conv_w[i];
       tab.wf[i] = ws + p.wf[i];
       tab.wd[i] = (i > 0 && d->save_for_backward) ? ws + p.wd[i] : (float*)nullptr;
+      tab.wf16[i] = (b16 && i > 0) ? reinterpret_cast<__bf16*>(ws + p.wf16[i]) : (__bf16*)nullptr;
+      tab.wd16[i] = (b16 && i > 0 && d->save_for_backward) ? reinterpret_cast<__bf16*>(ws + p.wd16[i]) : (__bf16*)nullptr;
       tab.cout[i] = c.cout; tab.cin[i] = c.cin; tab.ks[i] = c.ks;
       tab.blk0[i] = nb;
       nb += i == 0 ? cdiv(64 * 49, 256) : (c.cout / 32) * (c.cin / 32);
@@ -758,10 +924,19 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
   if ((rc = conv_fwd(frames, ws + p.wf[0], ws + p.c0, p.geom[0], s, ws + p.slab))) return rc;
   const long M0 = N * p.h[1] * p.w[1];
   if ((rc = bn_prepare(&p, ws, 0, ws + p.c0, M0, prm, d, s))) return rc;
-  hipLaunchKernelGGL(stem_bn_relu_pool, dim3(ew_grid(N * p.h[2] * p.w[2] * 16)), dim3(256), 0, s, ws + p.c0,
-                     ws + p.bn_scale, ws + p.bn_shift, ws + p.p0,
-                     d->save_for_backward ? reinterpret_cast<unsigned*>(ws + p.am) : (unsigned*)nullptr, d->N, p.h[1], p.w[1],
-                     p.h[2], p.w[2]);
+  {
+    unsigned* am = d->save_for_backward ? reinterpret_cast<unsigned*>(ws + p.am) : (unsigned*)nullptr;
+    if (b16)
+      hipLaunchKernelGGL(stem_bn_relu_pool<true>, dim3(ew_grid(N * p.h[2] * p.w[2] * 16)), dim3(256), 0, s, ws + p.c0, ws + p.bn_scale,
+                         ws + p.bn_shift, ws + p.p0, am, d->N, p.h[1], p.w[1], p.h[2], p.w[2]);
+    else
+      hipLaunchKernelGGL(stem_bn_relu_pool<false>, dim3(ew_grid(N * p.h[2] * p.w[2] * 16)), dim3(256), 0, s, ws + p.c0, ws + p.bn_scale,
+                         ws + p.bn_shift, ws + p.p0, am, d->N, p.h[1], p.w[1], p.h[2], p.w[2]);
+  }
+  auto cfwd = [&](const float* xin, int i, float* yout) -> int {
+    if (b16) return conv_fwd16(xin, ws + p.wf16[i], yout, p.geom[i], s, ws + p.slab, fused_stat(&p, ws, i, d));
+    return conv_fwd(xin, ws + p.wf[i], yout, p.geom[i], s, ws + p.slab, fused_stat(&p, ws, i, d));
+  };
   // residual stages
   const float* x = ws + p.p0;
   int ci = 1;
@@ -775,27 +950,43 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
       const long nq = M * C / 4;
       const int i1 = ci, i2 = ci + 1, id = ci + 2;
       unsigned char* qmo = d->save_for_backward ? reinterpret_cast<unsigned char*>(ws + p.qm[st * 2 + b]) : (unsigned char*)nullptr;
-      if ((rc = conv_fwd(x, ws + p.wf[i1], ws + o[0], p.geom[i1], s, ws + p.slab))) return rc;
+      if ((rc = cfwd(x, i1, ws + o[0]))) return rc;
       if ((rc = bn_prepare(&p, ws, i1, ws + o[0], M, prm, d, s))) return rc;
-      hipLaunchKernelGGL(bn_act, dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[0], ws + p.bn_scale + i1 * MAXC,
-                         ws + p.bn_shift + i1 * MAXC, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
-                         ws + o[1], nq, C, 1);
-      if ((rc = conv_fwd(ws + o[1], ws + p.wf[i2], ws + o[2], p.geom[i2], s, ws + p.slab))) return rc;
+      if (b16)
+        hipLaunchKernelGGL((bn_act<true, false>), dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[0], ws + p.bn_scale + i1 * MAXC,
+                           ws + p.bn_shift + i1 * MAXC, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           ws + o[1], nq, C, 1, (unsigned char*)nullptr);
+      else
+        hipLaunchKernelGGL((bn_act<false, false>), dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[0], ws + p.bn_scale + i1 * MAXC,
+                           ws + p.bn_shift + i1 * MAXC, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                           ws + o[1], nq, C, 1, (unsigned char*)nullptr);
+      if ((rc = cfwd(ws + o[1], i2, ws + o[2]))) return rc;
       if ((rc = bn_prepare(&p, ws, i2, ws + o[2], M, prm, d, s))) return rc;
       if (ds) {
-        if ((rc = conv_fwd(x, ws + p.wf[id], ws + o[3], p.geom[id], s, ws + p.slab))) return rc;
+        if ((rc = cfwd(x, id, ws + o[3]))) return rc;
         if ((rc = bn_prepare(&p, ws, id, ws + o[3], M, prm, d, s))) return rc;
-        hipLaunchKernelGGL(bn_act, dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
-                           ws + p.bn_shift + i2 * MAXC, ws + o[3], ws + p.bn_scale + id * MAXC, ws + p.bn_shift + id * MAXC,
-                           ws + o[4], nq, C, 1, qmo);
+        // (the identity input is the downsample convolution's RAW fp32 output in either data path)
+        if (b16)
+          hipLaunchKernelGGL((bn_act<true, false>), dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
+                             ws + p.bn_shift + i2 * MAXC, ws + o[3], ws + p.bn_scale + id * MAXC, ws + p.bn_shift + id * MAXC,
+                             ws + o[4], nq, C, 1, qmo);
+        else
+          hipLaunchKernelGGL((bn_act<false, false>), dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
+                             ws + p.bn_shift + i2 * MAXC, ws + o[3], ws + p.bn_scale + id * MAXC, ws + p.bn_shift + id * MAXC,
+                             ws + o[4], nq, C, 1, qmo);
       } else {
-        hipLaunchKernelGGL(bn_act, dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
-                           ws + p.bn_shift + i2 * MAXC, x, (const float*)nullptr, (const float*)nullptr, ws + o[4], nq, C, 1, qmo);
+        if (b16)     // the identity input is the block's bf16 input
+          hipLaunchKernelGGL((bn_act<true, true>), dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
+                             ws + p.bn_shift + i2 * MAXC, x, (const float*)nullptr, (const float*)nullptr, ws + o[4], nq, C, 1, qmo);
+        else
+          hipLaunchKernelGGL((bn_act<false, false>), dim3(ew_grid(nq)), dim3(256), 0, s, ws + o[2], ws + p.bn_scale + i2 * MAXC,
+                             ws + p.bn_shift + i2 * MAXC, x, (const float*)nullptr, (const float*)nullptr, ws + o[4], nq, C, 1, qmo);
       }
       x = ws + o[4];
       ci += ds ? 3 : 2;
     }
-  hipLaunchKernelGGL(avgpool_fwd, dim3(ew_grid(N * 512)), dim3(256), 0, s, x, feat, d->N, p.h[5] * p.w[5], 512);
+  if (b16) hipLaunchKernelGGL(avgpool_fwd<true>, dim3(ew_grid(N * 512)), dim3(256), 0, s, x, feat, d->N, p.h[5] * p.w[5], 512);
+  else hipLaunchKernelGGL(avgpool_fwd<false>, dim3(ew_grid(N * 512)), dim3(256), 0, s, x, feat, d->N, p.h[5] * p.w[5], 512);
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }
@@ -820,9 +1011,16 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
   // d(out of last block) from the average pool
   hipLaunchKernelGGL(avgpool_bwd, dim3(ew_grid(N * p.h[5] * p.w[5] * 512)), dim3(256), 0, s, dfeat, G0, d->N,
                      p.h[5] * p.w[5], 512);
+  const bool b16 = native_bf16();        // the forward ran the bf16 data path (same process-wide option): activations,
+                                         // and the BatchNorm-backward outputs that feed convolutions, are bf16
   auto wgrad = [&](int i, const float* xin, const float* dyraw) -> int {
     if (!g->conv_w[i]) return AVVAD_OK;
+    if (b16 && i > 0) return conv_wgrad16(xin, dyraw, ws + p.wg[i], p.geom[i], s, ws + p.slab);
     return conv_wgrad(xin, dyraw, ws + p.wg[i], p.geom[i], s, ws + p.slab);   // unpacked at the end (unpack_all)
+  };
+  auto dgrad = [&](const float* dyv, int i, float* dxv, int accumulate) -> int {
+    if (b16) return conv_dgrad16(dyv, ws + p.wd16[i], dxv, p.geom[i], accumulate, s, ws + p.slab);
+    return conv_dgrad(dyv, ws + p.wd[i], dxv, p.geom[i], accumulate, s, ws + p.slab);
   };
   int ci = NCONV;
   for (int st = 3; st >= 0; --st)
@@ -837,20 +1035,20 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
       const unsigned char* qmb = reinterpret_cast<const unsigned char*>(ws + p.qm[st * 2 + b]);
       // G0 = d(block output, post-ReLU).  main branch: BN2 backward (mask out>0) -> d c2 in G1
       if (ds) {
-        if ((rc = bn_backward(&p, ws, i2, ws + o[2], G0, ws + o[4], G1, nullptr, M, prm, g, d, s, false, qmb))) return rc;
+        if ((rc = bn_backward(&p, ws, i2, ws + o[2], G0, ws + o[4], G1, nullptr, M, prm, g, d, s, false, qmb, b16))) return rc;
         // identity branch through downsample BN + 1x1 conv: d cd in G2, d x in G3
-        if ((rc = bn_backward(&p, ws, id, ws + o[3], G0, ws + o[4], G2, nullptr, M, prm, g, d, s, false, qmb))) return rc;
+        if ((rc = bn_backward(&p, ws, id, ws + o[3], G0, ws + o[4], G2, nullptr, M, prm, g, d, s, false, qmb, b16))) return rc;
         if ((rc = wgrad(id, x, G2))) return rc;
-        if ((rc = conv_dgrad(G2, ws + p.wd[id], G3, p.geom[id], 0, s, ws + p.slab))) return rc;
+        if ((rc = dgrad(G2, id, G3, 0))) return rc;
       } else {
         // identity branch: d x = masked d out (written to G3 by the apply kernel)
-        if ((rc = bn_backward(&p, ws, i2, ws + o[2], G0, ws + o[4], G1, G3, M, prm, g, d, s, false, qmb))) return rc;
+        if ((rc = bn_backward(&p, ws, i2, ws + o[2], G0, ws + o[4], G1, G3, M, prm, g, d, s, false, qmb, b16))) return rc;
       }
       if ((rc = wgrad(i2, ws + o[1], G1))) return rc;
-      if ((rc = conv_dgrad(G1, ws + p.wd[i2], G2, p.geom[i2], 0, s, ws + p.slab))) return rc;  // d a1 in G2
-      if ((rc = bn_backward(&p, ws, i1, ws + o[0], G2, ws + o[1], G1, nullptr, M, prm, g, d, s, true))) return rc;  // d c1 in G1
+      if ((rc = dgrad(G1, i2, G2, 0))) return rc;  // d a1 in G2
+      if ((rc = bn_backward(&p, ws, i1, ws + o[0], G2, ws + o[1], G1, nullptr, M, prm, g, d, s, true, nullptr, b16))) return rc;  // d c1 in G1
       if ((rc = wgrad(i1, x, G1))) return rc;
-      if ((rc = conv_dgrad(G1, ws + p.wd[i1], G3, p.geom[i1], 1, s, ws + p.slab))) return rc;  // d x += ...
+      if ((rc = dgrad(G1, i1, G3, 1))) return rc;  // d x += ...
       float* t = G0; G0 = G3; G3 = t;
     }
   // stem: G0 = d p0

@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) chan_sum_acc(const float* __restrict__ dy
     if (threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o];
     __syncthreads();
   }
-  if (threadIdx.x == 0) atomicAdd(db + c, sm[0]);
+  if (threadIdx.x == 0) db[c] += sm[0];     // gridDim.y == 1: one workgroup per channel, a fixed summation order
 }
 
 // Causal layer (few input channels, Cin*fw <= 4 weights per output channel): weight AND bias gradient in one pass over dy
@@ -1810,7 +1810,9 @@ static int wgrad_conv1d(const float* dy, const float* x, float* dw, int B, int C
 
 static void bias_grad(const float* dy, float* db, int B, int C, int L, hipStream_t s) {
   if (!db) return;
-  hipLaunchKernelGGL(chan_sum_acc, dim3(C, B < 64 ? B : 64), dim3(256), 0, s, dy, db, B, C, L);
+  // (one workgroup per channel: with several per channel adding atomically the sum depended on their arrival order --
+  //  the one gradient of the generic encoder path that was not bit-reproducible run to run)
+  hipLaunchKernelGGL(chan_sum_acc, dim3(C, 1), dim3(256), 0, s, dy, db, B, C, L);
 }
 
 }  // namespace

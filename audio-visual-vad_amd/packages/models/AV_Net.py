@@ -51,6 +51,7 @@ class DeepVAD_AV(nn.Module):
             # until the fusion: run the encoder on a side HIP stream so the two kinds of kernel share the chip.
             # autograd replays each backward node on its forward stream, so the backward passes overlap the same way.
             main, side = torch.cuda.current_stream(), ops.side_stream()
+            ops.note_fork(main)
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 audio = ops.TransposeLast2Fn.apply(self.wavenet_en(audio))        # (B,T,Bn)

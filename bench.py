@@ -271,7 +271,7 @@ def parity_probe(torch, model):
     with torch.no_grad():
         y = model(wave.cuda(), video.cuda(), torch.LongTensor(lens))
     model.load_state_dict(rs, strict=False)                      # the probe must not move the running statistics
-    return float((y.detach().cpu() - ref).abs().max())
+    return float((y.detach().cpu() - ref).abs().max()), float(ref.abs().max())
 
 
 def bench_c1(args):
@@ -493,7 +493,7 @@ def main():
             log("roofline probes done")
             if world == 1 and kind == "av":     # CPU baseline and CPU-reference delta: rank 0 at N=1 only
                 # (bf16: the delta of the bf16 arithmetic to the fp32 CPU reference, BASELINE configs[4]'s own tolerance applies)
-                out["cpu_ref_max_abs_delta"] = parity_probe(torch, model)
+                out["cpu_ref_max_abs_delta"], out["cpu_ref_max_abs"] = parity_probe(torch, model)
                 log("parity probe done")
                 out["cpu_baseline"] = cpu_baseline(torch)
                 log("cpu baseline done")

@@ -40,7 +40,7 @@ typedef void* avvad_stream_t; /* hipStream_t */
 /* library / build identification ("gfx950", ABI version).  AVVAD_ABI_VERSION is what THIS header describes; a binding
  * must refuse a library whose avvad_abi_version() differs (signatures changed incompatibly between versions:
  * 2 = (ws, ws_bytes) in front of the stream of avvad_gemm_f32 / avvad_conv2d_*, avvad_wavenet_desc.shared_device). */
-#define AVVAD_ABI_VERSION 2
+#define AVVAD_ABI_VERSION 3   /* 3 = + avvad_conv2d_*_bf16 */
 const char* avvad_version(void);
 int avvad_abi_version(void);
 
@@ -51,8 +51,11 @@ int avvad_abi_version(void);
  *   "wn_flat" (encoder block forward: 0 by plane length, 1 flat dword kernel, 2 buffer dword kernel with resident
  *   weights, 3 dwordx4 kernel, 4 high-occupancy kernel), "wn_dx" / "wn_bwd_t" (0 by the descriptor's shared_device hint, other values force
  *   a form), "wn_grid" (workgroup cap of the encoder block kernels),
- *   "bf16" (bf16-input MFMA with fp32 accumulation for the trunk convolutions and the dense GEMMs -- BASELINE config 5's
- *   mixed precision; storage, BatchNorm statistics, LSTM cell, loss and Adam stay fp32; never the default),
+ *   "bf16" (BASELINE config 5's mixed precision, never the default.  1: the trunk runs its bf16 DATA PATH -- activations
+ *   between convolutions, the gradients that feed convolutions and the packed weights are stored as bf16, the convolutions
+ *   run on the bf16 engine -- and the dense GEMMs of the heads round their fp32 operands to bf16 on their way into LDS;
+ *   2: round 2's form, fp32 storage everywhere and operands rounded while staging.  BatchNorm statistics, LSTM cell, loss,
+ *   Adam and every accumulation stay fp32 in both),
  *   "max_cus" (cap on the CUs a persistent grid occupies, so that RCCL's kernels find free CUs during data-parallel
  *   training).
  * Initial values come from AVVAD_<NAME> in the environment, read once.  Returns AVVAD_EINVAL for an unknown name. */
@@ -203,6 +206,20 @@ int avvad_conv2d_dgrad(const float* dy, const float* wd, float* dx, const avvad_
                        int accumulate, void* ws, size_t ws_bytes, avvad_stream_t s);
 int avvad_conv2d_wgrad(const float* x, const float* dy, float* dw_packed, const avvad_conv_desc* d, void* ws,
                        size_t ws_bytes, avvad_stream_t s);
+
+/* The same convolutions on the bf16 data path (BASELINE configs[4]; what the trunk runs when option "bf16" is 1): operands
+ * are bf16 IN MEMORY -- x16 / dy16 NHWC bf16, weights in the K-contiguous bf16 packs
+ *   wf16[co][(cc * T + tap) * 64 + r] = w[co][cc * 64 + r][tap]     (forward; T = KS * KS taps, 64-channel chunks cc)
+ *   wd16[c][(cc * T + tap) * 64 + r]  = w[cc * 64 + r][c][tap]      (data gradient; may be NULL in the pack call)
+ * -- multiplied by v_mfma_f32_32x32x16_bf16 with fp32 accumulation; results (y, dx, the packed weight gradient
+ * [(kh,kw,c)][co]) are fp32.  C and Co must be multiples of 64.  Same replaced call site as above. */
+int avvad_conv2d_pack_weights_bf16(const float* w_oihw, void* wf16, void* wd16, const avvad_conv_desc* d, avvad_stream_t s);
+int avvad_conv2d_fwd_bf16(const void* x16, const void* wf16, float* y, const avvad_conv_desc* d, void* ws, size_t ws_bytes,
+                          avvad_stream_t s);
+int avvad_conv2d_dgrad_bf16(const void* dy16, const void* wd16, float* dx, const avvad_conv_desc* d, int accumulate,
+                            void* ws, size_t ws_bytes, avvad_stream_t s);
+int avvad_conv2d_wgrad_bf16(const void* x16, const void* dy16, float* dw_packed, const avvad_conv_desc* d, void* ws,
+                            size_t ws_bytes, avvad_stream_t s);
 
 size_t avvad_trunk_workspace(const avvad_trunk_desc* d);
 /* Test support: offset (floats), channels and spatial size of the post-ReLU activation `index` that a forward run with

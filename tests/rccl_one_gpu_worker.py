@@ -35,15 +35,18 @@ def run(use_reducer, dev):
         loss.backward()
         if red is not None:
             launched_from_hooks = sum(red.launched)
+            launched_list = list(red.launched)
             red.finish()
         if step < 2:
             opt.step()
             opt.zero_grad()
     torch.cuda.synchronize()
-    info = {}
+    names = [n_ for n_, p_ in model.named_parameters() if p_.requires_grad]
+    info = {"names": names, "offsets": list(opt.offsets)}
     if red is not None:
-        info = {"buckets": len(red.buckets), "launched_from_hooks_last_step": launched_from_hooks,
-                "absent": sorted(red.absent)}
+        info.update({"buckets": len(red.buckets), "launched_from_hooks_last_step": launched_from_hooks,
+                     "absent": sorted(red.absent), "bucket_ranges": [list(b) for b in red.buckets],
+                     "not_launched": [i for i, l in enumerate(launched_list) if not l]})
         red.close()
     return opt.flat_grad.detach().clone(), float(loss.detach()), info
 
@@ -55,8 +58,19 @@ def main():
     assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    g1, l1, info = run(True, dev)
     g0, l0, _ = run(False, dev)
+    g1, l1, info = run(True, dev)
+    g2, l2, _ = run(False, dev)
+    # diagnostics: which parameters' gradients differ between the runs (none expected)
+    diff = {}
+    for tag, a, b in (("with_vs_without", g1, g0), ("without_vs_without", g2, g0)):
+        bad = []
+        for i, n_ in enumerate(info["names"]):
+            sl = slice(info["offsets"][i], info["offsets"][i + 1])
+            if not torch.equal(a[sl], b[sl]):
+                bad.append((n_, float((a[sl] - b[sl]).abs().max()), float(b[sl].abs().max())))
+        diff[tag] = bad
+    info["diff"] = diff
     torch.save({"with": g1.cpu(), "without": g0.cpu(), "loss": (l1, l0), "info": info}, out)
     dist.barrier()
     dist.destroy_process_group()
