@@ -178,8 +178,13 @@ def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
         wf = torch.randn(ks * ks * c, co, device="cuda") * 0.05
         y = torch.empty(n_frames, ho, ho, co, device="cuda")
         d = L.ConvDesc(n_frames, h, w, c, co, ks, stride, pad)
-        L.check(lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), L.ptr(ews), ews.numel() * 4, st), "conv fwd")
-        ms = _events(torch, lambda: lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), L.ptr(ews), ews.numel() * 4, st), reps)
+        if dtype == "bf16":          # the bf16 data path's kernel: operands bf16 in HBM (csrc/bgemm.h)
+            x, wf = x.bfloat16(), wf.bfloat16()
+            fn = lib.avvad_conv2d_fwd_bf16
+        else:
+            fn = lib.avvad_conv2d_fwd
+        L.check(fn(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), L.ptr(ews), ews.numel() * 4, st), "conv fwd")
+        ms = _events(torch, lambda: fn(L.ptr(x), L.ptr(wf), L.ptr(y), C.byref(d), L.ptr(ews), ews.numel() * 4, st), reps)
         flop = 2.0 * n_frames * ho * ho * co * ks * ks * c
         per.append((c, co, h, ks, stride, ms, flop / ms / 1e9))
         tot_flop += flop
@@ -187,8 +192,11 @@ def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
         n_launch += 1
     ach = tot_flop / tot_ms / 1e9
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
-    return {"bound": "mfma", "kernel": "igemm::kernel<128,128,true,512,Im2colFwd<true>,ColTapRows<true>,EpiStore%s> (trunk conv forward, Cout>=128, buffer-addressed gathers) + its "
-                                       "stream-K fix-up" % (",bf16" if dtype == "bf16" else ""),
+    kname = ("bgemm::kernel<128,128,false,Im2colFwd<true>,RowPairs,EpiStore> (trunk conv forward on the bf16 data path, Cout>=128: bf16 operands "
+             "in HBM, v_mfma_f32_32x32x16_bf16) + its stream-K fix-up" if dtype == "bf16" else
+             "igemm::kernel<128,128,true,512,Im2colFwd<true>,ColTapRows<true>,EpiStore> (trunk conv forward, Cout>=128, buffer-addressed gathers) + its "
+             "stream-K fix-up")
+    return {"bound": "mfma", "kernel": kname,
             "launches_per_step": n_launch, "avg_launch_us": round(1e3 * tot_ms / n_launch, 2),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": TRAFFIC.get("conv_fwd") if dtype == "f32" else None,
