@@ -267,6 +267,36 @@ __global__ void __launch_bounds__(256, 2)
         }
       continue;
     }
+    // (BEFORE the output stores: the LDS exchange needs a workgroup barrier, and a barrier behind the stores would wait for
+    //  every one of them to drain -- s_waitcnt vmcnt(0) -- on every tile)
+    if constexpr (HasStat<Epi>::value) {   // fused BatchNorm statistics of tiles finished here (igemm.h, EpiStore::stat)
+      if (E.stat != nullptr && kt0 == 0 && kt1 == ktiles) {
+        double* red = reinterpret_cast<double*>(smem);          // [2][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float sf = 0.f, qf = 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sf += v; qf = fmaf(v, v, qf); }
+          double sd = (double)sf, qd = (double)qf;
+          sd += __shfl_xor(sd, 32, 64);
+          qd += __shfl_xor(qd, 32, 64);
+          if (lh_e == 0) {
+            const int cl = wn * (BN / 2) + j * 32 + li_e;
+            red[(wm * BN + cl) * 2 + 0] = sd;
+            red[(wm * BN + cl) * 2 + 1] = qd;
+          }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < N) {
+          const double a0 = red[t * 2 + 0] + red[(BN + t) * 2 + 0], b0 = red[t * 2 + 1] + red[(BN + t) * 2 + 1];
+          const long tm = tile / ntn;
+          E.stat[(tm * 2 + 0) * N + n0 + t] = a0;
+          E.stat[(tm * 2 + 1) * N + n0 + t] = b0;
+        }
+      }
+    }
     bool fast = false;
     if constexpr (IsPlain<Epi>::value) fast = E.cs == 1 && (long)M * E.ldc < (1L << 31) && m0 + BM <= M && n0 + BN <= N;
 #pragma unroll
@@ -303,34 +333,6 @@ __global__ void __launch_bounds__(256, 2)
           }
         }
       }
-    if constexpr (HasStat<Epi>::value) {   // fused BatchNorm statistics of tiles finished here (igemm.h, EpiStore::stat)
-      if (E.stat != nullptr && kt0 == 0 && kt1 == ktiles) {
-        double* red = reinterpret_cast<double*>(smem);          // [2][BN][2]
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float sf = 0.f, qf = 0.f;
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sf += v; qf = fmaf(v, v, qf); }
-          double sd = (double)sf, qd = (double)qf;
-          sd += __shfl_xor(sd, 32, 64);
-          qd += __shfl_xor(qd, 32, 64);
-          if (lh_e == 0) {
-            const int cl = wn * (BN / 2) + j * 32 + li_e;
-            red[(wm * BN + cl) * 2 + 0] = sd;
-            red[(wm * BN + cl) * 2 + 1] = qd;
-          }
-        }
-        __syncthreads();
-        if (t < BN && n0 + t < N) {
-          const double a0 = red[t * 2 + 0] + red[(BN + t) * 2 + 0], b0 = red[t * 2 + 1] + red[(BN + t) * 2 + 1];
-          const long tm = tile / ntn;
-          E.stat[(tm * 2 + 0) * N + n0 + t] = a0;
-          E.stat[(tm * 2 + 1) * N + n0 + t] = b0;
-        }
-      }
-    }
   }
 }
 

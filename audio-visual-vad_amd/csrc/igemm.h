@@ -554,6 +554,44 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
         }
       continue;
     }
+    // (BEFORE the output stores: the LDS exchange needs a workgroup barrier, and a barrier behind the stores would wait for
+    //  every one of them to drain -- s_waitcnt vmcnt(0) -- on every tile)
+    if constexpr (HasStat<Epi>::value) {
+      // Fused BatchNorm statistics (see EpiStore::stat): this worker finished the tile by itself, so the sums are final.
+      // Lane (li, lh) holds column n of its wave's TN column blocks and rows (r, lh) of TM x 16 registers: 16 * TM terms in
+      // fp32, then doubles -- across the lane halves by a cross-lane move, across the WGM row waves through LDS (free: every
+      // wave is past the K loop's last barrier), in a fixed order.  Rows beyond M hold exact zeros (their operand rows were
+      // out of range) and add nothing.
+      if (E.stat != nullptr && kt0 == 0 && kt1 == ktiles) {
+        double* red = reinterpret_cast<double*>(smem);          // [WGM][BN][2]
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          float sf = 0.f, qf = 0.f;
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sf += v; qf = fmaf(v, v, qf); }
+          double sd = (double)sf, qd = (double)qf;
+          sd += __shfl_xor(sd, 32, 64);
+          qd += __shfl_xor(qd, 32, 64);
+          if (lh_e == 0) {
+            const int cl = wn * (BN / WGN) + j * 32 + li_e;
+            red[(wm * BN + cl) * 2 + 0] = sd;
+            red[(wm * BN + cl) * 2 + 1] = qd;
+          }
+        }
+        __syncthreads();
+        if (t < BN && n0 + t < N) {
+          double a = 0, b = 0;
+#pragma unroll
+          for (int w = 0; w < WGM; ++w) { a += red[(w * BN + t) * 2 + 0]; b += red[(w * BN + t) * 2 + 1]; }
+          const long tm = tile / ntn;
+          E.stat[(tm * 2 + 0) * N + n0 + t] = a;
+          E.stat[(tm * 2 + 1) * N + n0 + t] = b;
+        }
+        // (no barrier behind the reads: the next segment's prologue has one in front of its first LDS write)
+      }
+    }
     // Whole tile, or the piece that starts the tile's K range (it owns the output until the fix-up kernel runs): plain
     // stores.  The column's bias is fetched once (a load + wait per element costs a memory round trip each).  Plain
     // row-major outputs that fit 32-bit offsets take the fast path: interior tiles skip the per-element range checks
@@ -601,42 +639,6 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
           }
         }
       }
-    if constexpr (HasStat<Epi>::value) {
-      // Fused BatchNorm statistics (see EpiStore::stat): this worker finished the tile by itself, so the sums are final.
-      // Lane (li, lh) holds column n of its wave's TN column blocks and rows (r, lh) of TM x 16 registers: 16 * TM terms in
-      // fp32, then doubles -- across the lane halves by a cross-lane move, across the WGM row waves through LDS (free: every
-      // wave is past the K loop's last barrier), in a fixed order.  Rows beyond M hold exact zeros (their operand rows were
-      // out of range) and add nothing.
-      if (E.stat != nullptr && kt0 == 0 && kt1 == ktiles) {
-        double* red = reinterpret_cast<double*>(smem);          // [WGM][BN][2]
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          float sf = 0.f, qf = 0.f;
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; sf += v; qf = fmaf(v, v, qf); }
-          double sd = (double)sf, qd = (double)qf;
-          sd += __shfl_xor(sd, 32, 64);
-          qd += __shfl_xor(qd, 32, 64);
-          if (lh_e == 0) {
-            const int cl = wn * (BN / WGN) + j * 32 + li_e;
-            red[(wm * BN + cl) * 2 + 0] = sd;
-            red[(wm * BN + cl) * 2 + 1] = qd;
-          }
-        }
-        __syncthreads();
-        if (t < BN && n0 + t < N) {
-          double a = 0, b = 0;
-#pragma unroll
-          for (int w = 0; w < WGM; ++w) { a += red[(w * BN + t) * 2 + 0]; b += red[(w * BN + t) * 2 + 1]; }
-          const long tm = tile / ntn;
-          E.stat[(tm * 2 + 0) * N + n0 + t] = a;
-          E.stat[(tm * 2 + 1) * N + n0 + t] = b;
-        }
-        // (no barrier behind the reads: the next segment's prologue has one in front of its first LDS write)
-      }
-    }
 #ifdef AVVAD_PROF
     const unsigned long long tp3 = PROF_T();
     PROF_ADD(0, 1); PROF_ADD(1, tp1 - tp0); PROF_ADD(2, tp2 - tp1); PROF_ADD(3, tbar); PROF_ADD(4, tstage); PROF_ADD(5, tp3 - tp2);

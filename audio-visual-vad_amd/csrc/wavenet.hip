@@ -451,6 +451,108 @@ __global__ void __launch_bounds__(256, 4)
   }
 }
 
+// LDS-DMA form.  What bounds the dword kernels above is the CU's ADDRESS unit, shared by the four SIMDs: a wave memory
+// instruction costs it ~16 cycles whatever its width, a 32-sample tile issues 64 of them (32 operand loads, 16 residual loads,
+// 16 stores) = ~1000 cycles per tile and CU against 768 cycles of matrix work (48 MFMAs x 64 cycles / 4 SIMDs) -- the memory
+// phase alone takes 20 us per bench-shape layer (12 200 tiles / 256 CUs x 1024 cycles), and at launch every resident wave
+// queues its 48 loads at once, so the first MFMA of a CU waits for ~12 000 cycles of address work.  Here a tile's operands
+// arrive by EIGHT buffer_load_dwordx4 ... lds instructions (1 KiB each: 8 channel rows x 128 B, straight into the wave's own
+// 8 KB LDS tile, no VGPR destination): tap 0 and tap 1 as two [32 channels][32 samples] images.  The MFMA B operand of
+// k-step s is then one conflict-free ds_read_b32 (lane half h = tap h, row s), the residual rows are 16 more reads of the
+// tap-1 image, and the address unit sees 8 + 16 instructions per tile (384 cycles) -- the kernel is bound by the matrix
+// pipe.  Same MFMA sequence and accumulator initialisation as wn_block_fwd_occ: the results agree bit for bit.
+// One workgroup = 8 waves (weights once per workgroup in LDS, 64 KB of wave tiles): two per CU = 4 waves per SIMD.
+__global__ void __launch_bounds__(512, 4)
+    wn_block_fwd_dma(const float* __restrict__ s_in, const float* __restrict__ w_dil, const float* __restrict__ b_dil,
+                     const float* __restrict__ w_dense, const float* __restrict__ b_dense, float* __restrict__ s_out, int B, int Lin,
+                     int dil) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int Lo = Lin - dil;
+  const int tiles_per_seq = (Lo + 31) >> 5;
+  const int ntiles = B * tiles_per_seq;
+  __shared__ __attribute__((aligned(16))) float wl[8 * 2048 + 32 * 65 + 32 * 33 + 64];     // wave tiles first (16-byte aligned DMA targets)
+  float* const wts = wl + 8 * 2048;
+  for (int i = threadIdx.x; i < 2048; i += 512) wts[(i >> 6) * 65 + (i & 63)] = w_dil[i];
+  for (int i = threadIdx.x; i < 1024; i += 512) wts[2080 + (i >> 5) * 33 + (i & 31)] = w_dense[i];
+  if (threadIdx.x < 32) {
+    wts[3136 + threadIdx.x] = b_dil ? b_dil[threadIdx.x] : 0.f;
+    wts[3168 + threadIdx.x] = b_dense ? b_dense[threadIdx.x] : 0.f;
+  }
+  __syncthreads();
+  const float* wdl = wts + li * 65 + lh;              // W_dil[d = li][c = s][tap = lh] at wdl[2 s]
+  const float* wel = wts + 2080 + li * 33 + 4 * lh;   // W_dense[r = li][d = row(r', lh)] at wel[row(r', 0)]
+  const float* bzl = wts + 3136 + 4 * lh;
+  const float* bsl = wts + 3168 + 4 * lh;
+  const int rowL = Lin * 4, rowO = Lo * 4;
+  float* const tb = wl + __builtin_amdgcn_readfirstlane(wave) * 2048;        // this wave's tile: [tap][32 channels][32 samples]
+  const float* const xs = tb + lh * 1024 + li;                               // B operand of k-step s: xs[32 s]
+  const float* const rs = tb + 1024 + 4 * lh * 32 + li;                       // residual row (r, lh): rs[32 row(r, 0)]
+  // the DMA's per-lane source: channel row (lane >> 3) of the instruction's 8, samples 4 (lane & 7) .. + 3
+  const int dvo = (lane >> 3) * rowL + (lane & 7) * 16;
+  // tile walk: waves of one XCD sweep a contiguous eighth of the tiles (see xcd_walk; 8 waves per workgroup here)
+  int first = (int)(blockIdx.x * 8 + wave), last = ntiles, stride = (int)(gridDim.x * 8);
+  if ((gridDim.x & 7) == 0) {
+    const int xcd = blockIdx.x & 7;
+    first = (int)((long)ntiles * xcd / 8) + ((blockIdx.x >> 3) * 8 + wave);
+    last = (int)((long)ntiles * (xcd + 1) / 8);
+    stride = (gridDim.x >> 3) * 8;
+  }
+  first = __builtin_amdgcn_readfirstlane(first);
+  for (int tile = first; tile < last; tile += stride) {
+    const int b = tile / tiles_per_seq;
+    const int t0 = (tile - b * tiles_per_seq) * 32;
+    const __amdgpu_buffer_rsrc_t rx = brsrc(s_in + (long)b * 32 * Lin, 32 * rowL);
+    // samples past the end of a row read into the next row, past the slab nothing is written: garbage COLUMNS, whose
+    // results are never stored (an output column depends on its own input columns only)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(tb + q * 256), 16, dvo + t0 * 4,
+                                               8 * q * rowL, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(tb + 1024 + q * 256), 16,
+                                               dvo + (t0 + dil) * 4, 8 * q * rowL, 0, 0);
+    const int t = t0 + li;
+    const bool ok = t < Lo;
+    const int offo = ok ? t * 4 + 4 * lh * rowO : BUF_OOB;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = bzl[mfma32_row(r, 0)];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tile has landed (and the previous tile's stores have drained)
+    __builtin_amdgcn_sched_barrier(0);
+    // Operands of 8 k-steps at a time, the NEXT group's LDS reads in flight under this group's MFMAs (pinned: left alone,
+    // hipcc issues two reads, waits for them and multiplies twice -- the LDS latency in front of every MFMA pair)
+    float wv[2][8], xv[2][8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { wv[0][k] = wdl[2 * k]; xv[0][k] = xs[32 * k]; }
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      if (gq < 3) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { wv[(gq + 1) & 1][k] = wdl[2 * (8 * (gq + 1) + k)]; xv[(gq + 1) & 1][k] = xs[32 * (8 * (gq + 1) + k)]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc = mfma32(wv[gq & 1][k], relu1(xv[gq & 1][k]), acc);
+    }
+    // the 1x1 product: its 16 weights and the 16 residual rows are read while the last dilated MFMAs run
+    float we16[16];
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { we16[r] = wel[mfma32_row(r, 0)]; acc2[r] = bsl[mfma32_row(r, 0)] + rs[32 * mfma32_row(r, 0)]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2 = mfma32(we16[r], relu1(acc[r]), acc2);
+    const __amdgpu_buffer_rsrc_t ro = brsrc(s_out + (long)b * 32 * Lo, 32 * rowO);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) bstore(acc2[r], ro, offo, mfma32_row(r, 0) * rowO);
+    // (the next tile's DMA overwrites this wave's LDS tile: every read of it above has been consumed by an MFMA or an add
+    //  that precedes the DMA in program order)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // WIDE form (the default for planes of >= 128 samples): the same block with 16-byte memory instructions.  The dword
 // kernels above are ISSUE-bound in the memory pipe -- 64 one-dword wave-instructions per 32-sample tile keep the CU's
 // address unit busier (~1000 cycles) than the tile's 48 MFMAs keep the matrix pipe (768), and a wave that is stuck issuing
@@ -1775,6 +1877,14 @@ static void launch_block_fwd(const float* s_in, const float* wd, const float* bd
   long blocks = (ntiles + 3) / 4;
   if (blocks > 512) blocks = 512;    // 2 waves per SIMD resident; each wave walks >= 5 tiles at the bench shape
   if (avvad_tune().wn_grid > 0 && blocks > avvad_tune().wn_grid) blocks = avvad_tune().wn_grid;
+  if (buf_ok(B, Lin) && avvad_tune().wn_flat == 5 && Lo >= 32) {       // LDS-DMA form
+    long wb = (ntiles + 7) / 8;                       // 8 waves per workgroup, two workgroups per CU
+    if (wb > 512) wb = 512;
+    if (avvad_tune().wn_grid > 0 && wb > avvad_tune().wn_grid) wb = avvad_tune().wn_grid;
+    if (wb >= 8) wb = wb / 8 * 8 + ((wb & 7) ? 8 : 0);
+    hipLaunchKernelGGL(wn_block_fwd_dma, dim3((int)wb), dim3(512), 0, s, s_in, wd, bd, we, be, s_out, B, Lin, dil);
+    return;
+  }
   if (buf_ok(B, Lin) && (avvad_tune().wn_flat == 0 || avvad_tune().wn_flat == 4)) {
     long ob = (ntiles + 3) / 4;                       // 4 waves per SIMD resident: 1024 workgroups
     if (ob > 1024) ob = 1024;

@@ -1132,7 +1132,7 @@ def test_input_standardisation_in_the_train_loop():
                                              (256, 16000, 512, 0), (256, 15999, 1, 0), (64, 14977, 256, 0)])
 def test_wavenet_block_kernel_forms_agree(B, Lin, dil, grid, lib_options):
     """One residual block through avvad_wavenet_block_fwd in its three forms (option wn_flat: 1 flat dword addressing,
-    2 buffer dword, 3 wide dwordx4, 4 high occupancy) against the plain torch fp32 statement of the block (wavenet_autoencoder.py:78-86);
+    2 buffer dword, 3 wide dwordx4, 4 high occupancy, 5 LDS-DMA) against the plain torch fp32 statement of the block (wavenet_autoencoder.py:78-86);
     a small workgroup cap (wn_grid) makes every wave walk several tiles, tails included."""
     import ctypes as C
     import torch.nn.functional as F
@@ -1148,7 +1148,7 @@ def test_wavenet_block_kernel_forms_agree(B, Lin, dil, grid, lib_options):
         ref = (ref + s_in.double()[:, :, dil:]).float()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     outs = {}
-    for form in (1, 2, 3, 4):
+    for form in (1, 2, 3, 4, 5):
         lib_options("wn_flat", form)
         lib_options("wn_grid", grid)
         out = torch.full((B, 32, Lin - dil), float("nan"), device=DEV)
@@ -1161,6 +1161,7 @@ def test_wavenet_block_kernel_forms_agree(B, Lin, dil, grid, lib_options):
         assert (out - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item()), "form %d" % form
         outs[form] = out
     assert torch.equal(outs[1], outs[2]) and torch.equal(outs[1], outs[4])     # same arithmetic, different addressing
+    assert torch.equal(outs[1], outs[5])                                       # ... and the LDS-DMA form (operands through LDS)
 
 
 def _max_rel(a, b):
