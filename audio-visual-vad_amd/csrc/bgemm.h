@@ -24,9 +24,13 @@
 
 namespace bgemm {
 
+using igemm::ClassTile;
+using igemm::EpiCls;
 using igemm::EpiStore;
 using igemm::HasPrep2;
+using igemm::HasSched;
 using igemm::HasStat;
+using igemm::HasTile;
 using igemm::IsPlain;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -74,6 +78,25 @@ struct RowPairsSeg {
   }
 };
 
+// the packed weights for the live taps of a tile's position class (igemm.h "position classes"; conv_ops.h cls_tap)
+struct RowPairsCls {
+  static constexpr bool KCONTIG = true;
+  static constexpr int VEC = 4;
+  typedef igemm::NoCtx Ctx;
+  const float* p;
+  int ld, X, T, KS, NP, flip;
+  unsigned mg_NP;
+  igemm::ClassSched sc;
+  __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
+  __device__ __forceinline__ ClassTile tile(int m0) const { return igemm::class_tile(sc, igemm::dev_div(m0, mg_NP), flip != 0); }
+  __device__ __forceinline__ void load(const Ctx&, const ClassTile& t, int x, int k0, int kin, float* v) const {
+    int cc, kh, kw;
+    convop::cls_tap(t, k0, cc, kh, kw);
+    const f4v q = bload4(brsrc2g(p), x < X ? (int)(((unsigned)x * (unsigned)ld + (unsigned)((cc * T + kh * KS + kw) * 32 + kin)) * 4u) : BUF_OOB, 0);
+    v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+  }
+};
+
 template <int BM, int BN, bool MM, class AOp, class BOp, class Epi>
 __global__ void __launch_bounds__(256, 2)
     kernel(const AOp A, const BOp B, const Epi E, const int M, const int N, const int ktiles, const int full_rounds,
@@ -106,7 +129,8 @@ __global__ void __launch_bounds__(256, 2)
 
   const long G = gridDim.x;
   const long g = xcd_remap(blockIdx.x, gridDim.x);
-  const long rem_iters = (long)rem_tiles * ktiles;
+  long rem_iters = (long)rem_tiles * ktiles;
+  if constexpr (HasSched<Epi>::value) rem_iters = E.sched.total();      // position classes: every tile is in the pool
   long it = g * rem_iters / G;
   const long it_end = (g + 1) * rem_iters / G;
   const long ntiles_all = (long)((M + BM - 1) / BM) * ntn;
@@ -114,16 +138,21 @@ __global__ void __launch_bounds__(256, 2)
 
   for (;;) {
     int tile, kt0, kt1;
+    int klen = ktiles;
     if (round < full_rounds) {
       const long tl = (long)round * G + g;
       ++round;
       if (tl >= ntiles_all) continue;
       tile = (int)tl; kt0 = 0; kt1 = ktiles;
     } else if (it < it_end) {
-      const long tr = it / ktiles;
-      tile = (int)((long)full_rounds * G + tr);
-      kt0 = (int)(it - tr * ktiles);
-      kt1 = (int)min((long)ktiles, kt0 + (it_end - it));
+      if constexpr (HasSched<Epi>::value) {
+        E.sched.locate(it, tile, kt0, klen);
+      } else {
+        const long tr = it / ktiles;
+        tile = (int)((long)full_rounds * G + tr);
+        kt0 = (int)(it - tr * ktiles);
+      }
+      kt1 = (int)min((long)klen, kt0 + (it_end - it));
       it += kt1 - kt0;
     } else {
       break;
@@ -150,6 +179,10 @@ __global__ void __launch_bounds__(256, 2)
       else bctx[i] = B.prep(bx0 + xl);
     }
 
+    ClassTile atile, btile;
+    if constexpr (HasTile<AOp>::value) atile = A.tile(m0);
+    if constexpr (HasTile<BOp>::value) btile = B.tile(m0);
+    (void)atile; (void)btile;
     float sa[NVA][4], sb[NVB][4];
     auto gload = [&](int kt) {
       const int k0 = kt * BKU;
@@ -157,13 +190,15 @@ __global__ void __launch_bounds__(256, 2)
       for (int i = 0; i < NVA; ++i) {
         int xl, kl;
         coordA(i, xl, kl);
-        A.load(actx[NCA > 1 ? i : 0], ax0 + xl, k0, kl, sa[i]);
+        if constexpr (HasTile<AOp>::value) A.load(actx[NCA > 1 ? i : 0], atile, ax0 + xl, k0, kl, sa[i]);
+        else A.load(actx[NCA > 1 ? i : 0], ax0 + xl, k0, kl, sa[i]);
       }
 #pragma unroll
       for (int i = 0; i < NVB; ++i) {
         int xl, kl;
         coordB(i, xl, kl);
-        B.load(bctx[NCB > 1 ? i : 0], bx0 + xl, k0, kl, sb[i]);
+        if constexpr (HasTile<BOp>::value) B.load(bctx[NCB > 1 ? i : 0], btile, bx0 + xl, k0, kl, sb[i]);
+        else B.load(bctx[NCB > 1 ? i : 0], bx0 + xl, k0, kl, sb[i]);
       }
     };
     auto stage = [&](float* dst) {      // registers -> LDS, 16-byte stores, no conversion
@@ -270,7 +305,7 @@ __global__ void __launch_bounds__(256, 2)
     // (BEFORE the output stores: the LDS exchange needs a workgroup barrier, and a barrier behind the stores would wait for
     //  every one of them to drain -- s_waitcnt vmcnt(0) -- on every tile)
     if constexpr (HasStat<Epi>::value) {   // fused BatchNorm statistics of tiles finished here (igemm.h, EpiStore::stat)
-      if (E.stat != nullptr && kt0 == 0 && kt1 == ktiles) {
+      if (E.stat != nullptr && kt0 == 0 && kt1 == klen) {
         double* red = reinterpret_cast<double*>(smem);          // [2][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -297,19 +332,23 @@ __global__ void __launch_bounds__(256, 2)
         }
       }
     }
+    float* Cv = nullptr;                   // where the tile's rows live (position classes: the view of its grid position)
+    int mrow0 = m0, Mv = M;
+    if constexpr (HasSched<Epi>::value) { const auto v = E.view(m0); Cv = v.C; mrow0 = v.row0; Mv = v.M; }
+    else if constexpr (IsPlain<Epi>::value) Cv = E.C;
     bool fast = false;
-    if constexpr (IsPlain<Epi>::value) fast = E.cs == 1 && (long)M * E.ldc < (1L << 31) && m0 + BM <= M && n0 + BN <= N;
+    if constexpr (IsPlain<Epi>::value) fast = E.cs == 1 && (long)Mv * E.ldc < (1L << 31) && mrow0 + BM <= Mv && n0 + BN <= N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / 2) + j * 32 + li_e;
-        const int mb = m0 + wm * (BM / 2) + i * 32;
+        const int mb = mrow0 + wm * (BM / 2) + i * 32;
         if constexpr (IsPlain<Epi>::value) {
           if (fast) {
             const unsigned ld32 = (unsigned)E.ldc;
             const unsigned base = (unsigned)(mb + 4 * lh_e) * ld32 + (unsigned)n;
-            float* const Cb = E.C;
+            float* const Cb = Cv;
             if (E.mode == 0) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) Cb[base + (unsigned)mfma32_row(r, 0) * ld32] = acc[i][j][r];
@@ -326,8 +365,10 @@ __global__ void __launch_bounds__(256, 2)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mb + mfma32_row(r, lh_e);
-          if (m < M && n < N) {
-            float* const p = E.ptr(m, n);
+          if (m < Mv && n < N) {
+            float* p;
+            if constexpr (HasSched<Epi>::value) p = Cv + (long)m * E.ldc + n;
+            else p = E.ptr(m, n);
             if (E.mode == 0) *p = acc[i][j][r];
             else *p += acc[i][j][r];
           }
@@ -374,6 +415,30 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
     else
       hipLaunchKernelGGL((igemm::fixup<BM, BN, Epi>), dim3(rt * (BM * BN / 256)), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));
   }
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+// position-class product on the bf16 engine (igemm::launch_cls is the fp32 twin): 128x128 KK tiles
+template <class AOp, class BOp>
+static inline int launch_cls(const AOp& a, const BOp& b, const EpiCls& e, int Mp, int N, hipStream_t s, float* slab) {
+  constexpr int BM = 128, BN = 128;
+  if (Mp <= 0 || N <= 0 || !slab) return AVVAD_EINVAL;
+  const AvvadTune& tn = avvad_tune();
+  const long ntiles = (long)cdiv(Mp, BM) * cdiv(N, BN);
+  const int cus = (tn.max_cus > 0 && tn.max_cus < igemm::NUM_CU) ? tn.max_cus : igemm::NUM_CU;
+  long G = (long)cus * 2;
+  if (G * BM * BN > (long)igemm::SLAB_FLOATS) G = (long)(igemm::SLAB_FLOATS / ((size_t)BM * BN));
+  const long R = e.sched.total();
+  if (ntiles > G || ntiles != (long)e.sched.Ho * e.sched.Wo * e.sched.tpc || R <= 0 || (double)R * (double)G >= 4.0e9) return AVVAD_EINVAL;
+  if (G > R / 4) G = R / 4 > 0 ? R / 4 : 1;
+  if (e.stat && (e.cs != 1 || (e.ldc & 3) || (N & 3) || (((uintptr_t)e.C) & 15) || (e.W & 3))) return AVVAD_EINVAL;
+  hipLaunchKernelGGL((kernel<BM, BN, false, AOp, BOp, EpiCls>), dim3((int)G), dim3(256), 0, s, a, b, e, Mp, N, 1, 0, (int)ntiles, slab);
+  if (e.stat)
+    hipLaunchKernelGGL((igemm::fixup_tile<BM, BN, EpiCls>), dim3((int)ntiles), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0, (int)ntiles, cdiv(N, BN));
+  else
+    hipLaunchKernelGGL((igemm::fixup1<BM, BN, EpiCls>), dim3((int)ntiles * (BM * BN / 1024)), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0,
+                       (int)ntiles, cdiv(N, BN));
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

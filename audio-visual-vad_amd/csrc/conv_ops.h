@@ -308,6 +308,96 @@ struct WgradX {
   }
 };
 
+// ---- position-class operands (igemm.h "position classes"): GEMM rows are ordered grid-position-major, m' = p * NP + n, so
+// that a tile's rows share their set of live taps and the K loop walks only those -- no validity masks at all.  3x3 / pad 1.
+// K tile q of a tile of class (a x b live taps from (kh_lo, kw_lo)):  q = cc * (a b) + (kh - kh_lo) * b + (kw - kw_lo).
+__device__ __forceinline__ void cls_tap(const igemm::ClassTile& t, int k0, int& cc, int& kh, int& kw) {
+  const int q = k0 >> 5, ab = t.a * t.b;
+  cc = igemm::dev_div(q, t.mg_ab);
+  const int j = q - cc * ab, dkh = igemm::dev_div(j, t.mg_b);
+  kh = t.kh_lo + dkh;
+  kw = t.kw_lo + (j - dkh * t.b);
+}
+// forward A: classes = OUTPUT positions (ho, wo); row n of class p reads x[n, ho s - 1 + kh, wo s - 1 + kw, :]
+struct Im2colFwdCls {
+  static constexpr bool KCONTIG = true;
+  static constexpr int VEC = 4;
+  struct Ctx { unsigned boff; int ok; };
+  const float* x;
+  Geom g;
+  int NP, rows;
+  unsigned mg_NP;
+  igemm::ClassSched sc;
+  __device__ __forceinline__ Ctx prep(int m) const { return prep2(m, 0); }
+  __device__ __forceinline__ Ctx prep2(int m, int kin) const {
+    const int n = m - igemm::dev_div(m, mg_NP) * NP;
+    Ctx c;
+    c.ok = n < rows;
+    c.boff = ((unsigned)n * (unsigned)(g.H * g.W) * (unsigned)g.C + (unsigned)kin) * 4u;
+    return c;
+  }
+  __device__ __forceinline__ igemm::ClassTile tile(int m0) const { return igemm::class_tile(sc, igemm::dev_div(m0, mg_NP), false); }
+  __device__ __forceinline__ void load(const Ctx& c, const igemm::ClassTile& t, int, int k0, int, float* v) const {
+    int cc, kh, kw;
+    cls_tap(t, k0, cc, kh, kw);
+    const int hi = t.ho * g.stride - g.pad + kh, wi = t.wo * g.stride - g.pad + kw;         // inside the image by construction
+    const unsigned soff = ((unsigned)(hi * g.W + wi) * (unsigned)g.C + (unsigned)cc * 32u) * 4u;   // scalar
+    fetch4<true>(x, c.ok ? c.boff + soff : INVALID_OFF(true), v);
+  }
+};
+// data gradient A (stride 1): classes = INPUT positions (hi, wi); row n of class p reads dy[n, hi + 1 - kh, wi + 1 - kw, :]
+struct Im2colDgradCls {
+  static constexpr bool KCONTIG = true;
+  static constexpr int VEC = 4;
+  struct Ctx { unsigned boff; int ok; };
+  const float* dy;
+  Geom g;
+  int NP, rows;
+  unsigned mg_NP;
+  igemm::ClassSched sc;
+  __device__ __forceinline__ Ctx prep(int m) const { return prep2(m, 0); }
+  __device__ __forceinline__ Ctx prep2(int m, int kin) const {
+    const int n = m - igemm::dev_div(m, mg_NP) * NP;
+    Ctx c;
+    c.ok = n < rows;
+    c.boff = ((unsigned)n * (unsigned)(g.Ho * g.Wo) * (unsigned)g.Co + (unsigned)kin) * 4u;
+    return c;
+  }
+  __device__ __forceinline__ igemm::ClassTile tile(int m0) const { return igemm::class_tile(sc, igemm::dev_div(m0, mg_NP), true); }
+  __device__ __forceinline__ void load(const Ctx& c, const igemm::ClassTile& t, int, int k0, int, float* v) const {
+    int cc, kh, kw;
+    cls_tap(t, k0, cc, kh, kw);
+    const int ho = t.ho + g.pad - kh, wo = t.wo + g.pad - kw;
+    const unsigned soff = ((unsigned)(ho * g.Wo + wo) * (unsigned)g.Co + (unsigned)cc * 32u) * 4u;
+    fetch4<true>(dy, c.ok ? c.boff + soff : INVALID_OFF(true), v);
+  }
+};
+// packed weights [(tap, ch)][x] for the live taps of the tile's class (rows tap * C + cc * 32 + r)
+struct ColTapRowsCls {
+  static constexpr bool KCONTIG = false;
+  static constexpr int VEC = 4;
+  static constexpr bool PERVEC = true;
+  struct Ctx { unsigned boff; int ok; };
+  const float* p;
+  long ld;
+  int X, C, KS, NP, flip;
+  unsigned mg_NP;
+  igemm::ClassSched sc;
+  __device__ __forceinline__ Ctx prep(int x) const { return prep2(x, 0); }
+  __device__ __forceinline__ Ctx prep2(int x, int kl) const {
+    Ctx c;
+    c.ok = x < X;
+    c.boff = c.ok ? (unsigned)((kl * (int)ld + x) * 4) : 0u;
+    return c;
+  }
+  __device__ __forceinline__ igemm::ClassTile tile(int m0) const { return igemm::class_tile(sc, igemm::dev_div(m0, mg_NP), flip != 0); }
+  __device__ __forceinline__ void load(const Ctx& c, const igemm::ClassTile& t, int, int k0, int, float* v) const {
+    int cc, kh, kw;
+    cls_tap(t, k0, cc, kh, kw);
+    fetch4<true>(p, c.ok ? c.boff + (unsigned)(((kh * KS + kw) * C + cc * 32) * (int)ld * 4) : INVALID_OFF(true), v);
+  }
+};
+
 // ---- stem (C = 1): scalar gathers
 struct StemFwd {  // rows = output pixels, K = KS*KS (49), element = x[n, ho*2-3+kh, wo*2-3+kw]
   static constexpr bool KCONTIG = true;

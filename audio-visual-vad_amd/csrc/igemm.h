@@ -54,6 +54,109 @@ struct HasStat : std::false_type {};
 template <class Epi>
 struct HasStat<Epi, std::void_t<decltype(Epi::stat)>> : std::true_type {};
 
+// ---------------------------------------------------------------- position classes: skipping the zero padding
+// A 3x3 / pad 1 convolution multiplies structural zeros wherever a tap falls into the padding: 7 % of all products on a 17x17
+// grid, 14 % on 9x9, 25 % on 5x5 and 40 % on the 3x3 grid of the last stage (a corner pixel has 4 live taps of 9) -- on the
+// ResNet-18 trunk at 67x67 crops about a quarter of all convolution FLOPs.  They can be skipped, exactly (0 * w adds nothing),
+// when a tile's rows all sit at the SAME grid position: the GEMM's rows are therefore ordered position-major, m' = p * NP + n
+// (p = ho * Wo + wo, n = image, NP = images padded to a whole number of M tiles), so that the set of live taps is a property
+// of the TILE -- a(ho) x b(wo) taps, contiguous ranges kh_lo .. / kw_lo .. -- and a tile's K loop simply has fewer K tiles.
+// Tiles then differ in length: the stream-K round cuts the concatenation of all tiles' K tiles into equal shares, with the
+// tile <-> iteration maps in closed form (the live-tap counts are separable: a(ho) = KS - [ho == 0] fs - [ho == Ho-1] ls).
+// Used where the tile count does not exceed the worker count (no data-parallel rounds: every tile is in the pool).
+struct ClassSched {
+  int Ho, Wo, tpc, nchunk;        // grid of position classes; tiles per class (M tiles x N tiles); channel chunks per tap
+  int KS, fsh, lsh, fsw, lsw;     // first / last row (column) of the grid loses fsh / lsh (fsw / lsw) taps
+  __host__ __device__ int ah(int h) const { return KS - (h == 0 ? fsh : 0) - (h == Ho - 1 ? lsh : 0); }
+  __host__ __device__ int bw(int w) const { return KS - (w == 0 ? fsw : 0) - (w == Wo - 1 ? lsw : 0); }
+  __host__ __device__ int Ah(int h) const { return KS * h - (h > 0 ? fsh : 0) - (h > Ho - 1 ? lsh : 0); }   // sum of ah below h
+  __host__ __device__ int Bw(int w) const { return KS * w - (w > 0 ? fsw : 0) - (w > Wo - 1 ? lsw : 0); }
+  __host__ __device__ long total() const { return (long)nchunk * tpc * Ah(Ho) * Bw(Wo); }
+  __host__ __device__ int len(int tile) const {
+    const int p = tile / tpc, ho = p / Wo, wo = p - ho * Wo;
+    return ah(ho) * bw(wo) * nchunk;
+  }
+  __host__ __device__ long base(int tile) const {      // K tiles of all tiles in front of `tile`
+    const int p = tile / tpc, r = tile - p * tpc, ho = p / Wo, wo = p - ho * Wo;
+    return (long)nchunk * ((long)tpc * (Ah(ho) * Bw(Wo) + ah(ho) * Bw(wo)) + (long)r * ah(ho) * bw(wo));
+  }
+  __device__ void locate(long it, int& tile, int& kt, int& klen) const {
+    const long c = (long)nchunk * tpc;
+    const int Bt = Bw(Wo);
+    int ho = 0;
+    while (ho + 1 < Ho && c * Ah(ho + 1) * Bt <= it) ++ho;
+    long rem = it - c * Ah(ho) * Bt;
+    const int a = ah(ho);
+    int wo = 0;
+    while (wo + 1 < Wo && c * a * Bw(wo + 1) <= rem) ++wo;
+    rem -= c * a * Bw(wo);
+    klen = a * bw(wo) * nchunk;
+    const int r = (int)(rem / klen);
+    kt = (int)(rem - (long)r * klen);
+    tile = (ho * Wo + wo) * tpc + r;
+  }
+};
+// what a tile's K loop needs to know about its class: live tap ranges and counts (wave-uniform: kept in scalar registers)
+struct ClassTile {
+  int ho, wo, a, b, kh_lo, kw_lo;
+  unsigned mg_ab, mg_b;           // exact-division magics for a * b and b
+};
+__device__ __forceinline__ unsigned dev_magic(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
+__device__ __forceinline__ int dev_div(int k, unsigned mg) { return mg ? (int)__umulhi((unsigned)k, mg) : k; }
+// flip: the data gradient walks the taps the other way round (pixel = position + pad - tap): the first row loses the LAST tap
+__device__ __forceinline__ ClassTile class_tile(const ClassSched& s, int p, bool flip) {
+  ClassTile t;
+  t.ho = p / s.Wo;
+  t.wo = p - t.ho * s.Wo;
+  t.a = s.ah(t.ho);
+  t.b = s.bw(t.wo);
+  const int cut_h = flip ? (t.ho == s.Ho - 1 ? s.lsh : 0) : (t.ho == 0 ? s.fsh : 0);
+  const int cut_w = flip ? (t.wo == s.Wo - 1 ? s.lsw : 0) : (t.wo == 0 ? s.fsw : 0);
+  t.kh_lo = cut_h;
+  t.kw_lo = cut_w;
+  t.mg_ab = dev_magic(t.a * t.b);
+  t.mg_b = dev_magic(t.b);
+  return t;
+}
+// Epilogue of a position-class product: GEMM row m' = p * NP + n is row n of the [rows][ldc] view that starts at column
+// block p * W of the output (NHWC: pixel (n, p) -> C + (n * P + p) * W).  Carries the schedule (the fix-up kernels need it).
+struct EpiCls {
+  static constexpr bool PLAIN = true;
+  float* C;
+  long ldc;            // P * W: elements between consecutive images at one grid position
+  const float* bias;   // unused (null)
+  int mode;
+  int cs = 1;
+  double* stat = nullptr;
+  int W = 0;           // channels of the output (elements per pixel)
+  int NP = 0, rows = 0;  // padded / real images per class
+  unsigned mg_NP = 0;
+  ClassSched sched;
+  struct View { float* C; int row0, M; };
+  __device__ __forceinline__ View view(int m0) const {
+    const int p = dev_div(m0, mg_NP);
+    return View{C + (long)p * W, m0 - p * NP, rows};
+  }
+  __device__ __forceinline__ bool live(int m) const { return m - dev_div(m, mg_NP) * NP < rows; }
+  __device__ __forceinline__ float* ptr(int m, int n) const {
+    const int p = dev_div(m, mg_NP);
+    return C + (long)p * W + (long)(m - p * NP) * ldc + n;
+  }
+};
+template <class Epi, class = void>
+struct HasSched : std::false_type {};
+template <class Epi>
+struct HasSched<Epi, std::void_t<decltype(Epi::sched)>> : std::true_type {};
+template <class Op, class = void>
+struct HasTile : std::false_type {};
+template <class Op>
+struct HasTile<Op, std::void_t<decltype(&Op::tile)>> : std::true_type {};
+template <class Epi>
+__device__ __forceinline__ bool epi_live(const Epi& E, int m, int M) {
+  if constexpr (HasSched<Epi>::value) return m < M && E.live(m);
+  else return m < M;
+}
+
 // ---------------------------------------------------------------- dense operands
 // element (x, k) = p[x*ld + k]
 struct RowPlain {
@@ -348,7 +451,8 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
 #endif
   const long G = gridDim.x;
   const long g = xcd_remap(blockIdx.x, gridDim.x);
-  const long rem_iters = (long)rem_tiles * ktiles;
+  long rem_iters = (long)rem_tiles * ktiles;
+  if constexpr (HasSched<Epi>::value) rem_iters = E.sched.total();      // tiles of different lengths: every tile is in the pool
   long it = g * rem_iters / G;
   const long it_end = (g + 1) * rem_iters / G;
   const long ntiles_all = (long)((M + BM - 1) / BM) * ntn;
@@ -357,6 +461,7 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
 
   for (;;) {
     int tile, kt0, kt1;
+    int klen = ktiles;      // K tiles of this tile
     if (kchunks > 0) {
       // K-MAJOR CELLS (few tiles, long K: the conv weight gradients).  K is cut into kchunks ranges and the cells
       // (range, tile) are dealt out tile-fastest, so neighbouring workers -- one XCD after the remap -- contract the
@@ -375,10 +480,14 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
       if (tl >= ntiles_all) continue;                // last, partially filled round
       tile = (int)tl; kt0 = 0; kt1 = ktiles;
     } else if (it < it_end) {                        // stream-K round over the remainder tiles
-      const long tr = it / ktiles;
-      tile = (int)((long)full_rounds * G + tr);
-      kt0 = (int)(it - tr * ktiles);
-      kt1 = (int)min((long)ktiles, kt0 + (it_end - it));
+      if constexpr (HasSched<Epi>::value) {
+        E.sched.locate(it, tile, kt0, klen);
+      } else {
+        const long tr = it / ktiles;
+        tile = (int)((long)full_rounds * G + tr);
+        kt0 = (int)(it - tr * ktiles);
+      }
+      kt1 = (int)min((long)klen, kt0 + (it_end - it));
       it += kt1 - kt0;
     } else {
       break;
@@ -402,6 +511,12 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
       else bctx[i] = B.prep(n0 + xl);
     }
 
+    // position-class operands: what the tile's class means for its K loop (live taps), wave-uniform
+    ClassTile atile, btile;
+    if constexpr (HasTile<AOp>::value) atile = A.tile(m0);
+    if constexpr (HasTile<BOp>::value) btile = B.tile(m0);
+    (void)atile; (void)btile;
+
     float sa[SA::NV][SA::VEC], sb[SB::NV][SB::VEC];
     unsigned oka = ~0u, okb = ~0u;   // bit i: staged vector i holds a real element (see OPERAND CONTRACT)
     static_assert(SA::NV <= 32 && SB::NV <= 32, "validity masks are 32 bits");
@@ -411,23 +526,41 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
 #else
       const int k0 = kt * BK;
 #endif
-      constexpr bool AB = std::is_same<decltype(A.load(actx[0], 0, 0, 0, sa[0])), bool>::value;
-      constexpr bool BB = std::is_same<decltype(B.load(bctx[0], 0, 0, 0, sb[0])), bool>::value;
-      if (AB) oka = 0u;
-      if (BB) okb = 0u;
+      if constexpr (HasTile<AOp>::value) {           // (class operands: buffer form, nothing to return)
 #pragma unroll
-      for (int i = 0; i < SA::NV; ++i) {
-        int xl, kl;
-        SA::coord(t, i, xl, kl);
-        if constexpr (AB) oka |= (unsigned)A.load(actx[SA::NCTX > 1 ? i : 0], m0 + xl, k0, kl, sa[i]) << i;
-        else A.load(actx[SA::NCTX > 1 ? i : 0], m0 + xl, k0, kl, sa[i]);
+        for (int i = 0; i < SA::NV; ++i) {
+          int xl, kl;
+          SA::coord(t, i, xl, kl);
+          A.load(actx[SA::NCTX > 1 ? i : 0], atile, m0 + xl, k0, kl, sa[i]);
+        }
+      } else {
+        constexpr bool AB = std::is_same<decltype(A.load(actx[0], 0, 0, 0, sa[0])), bool>::value;
+        if (AB) oka = 0u;
+#pragma unroll
+        for (int i = 0; i < SA::NV; ++i) {
+          int xl, kl;
+          SA::coord(t, i, xl, kl);
+          if constexpr (AB) oka |= (unsigned)A.load(actx[SA::NCTX > 1 ? i : 0], m0 + xl, k0, kl, sa[i]) << i;
+          else A.load(actx[SA::NCTX > 1 ? i : 0], m0 + xl, k0, kl, sa[i]);
+        }
       }
+      if constexpr (HasTile<BOp>::value) {
 #pragma unroll
-      for (int i = 0; i < SB::NV; ++i) {
-        int xl, kl;
-        SB::coord(t, i, xl, kl);
-        if constexpr (BB) okb |= (unsigned)B.load(bctx[SB::NCTX > 1 ? i : 0], n0 + xl, k0, kl, sb[i]) << i;
-        else B.load(bctx[SB::NCTX > 1 ? i : 0], n0 + xl, k0, kl, sb[i]);
+        for (int i = 0; i < SB::NV; ++i) {
+          int xl, kl;
+          SB::coord(t, i, xl, kl);
+          B.load(bctx[SB::NCTX > 1 ? i : 0], btile, n0 + xl, k0, kl, sb[i]);
+        }
+      } else {
+        constexpr bool BB = std::is_same<decltype(B.load(bctx[0], 0, 0, 0, sb[0])), bool>::value;
+        if (BB) okb = 0u;
+#pragma unroll
+        for (int i = 0; i < SB::NV; ++i) {
+          int xl, kl;
+          SB::coord(t, i, xl, kl);
+          if constexpr (BB) okb |= (unsigned)B.load(bctx[SB::NCTX > 1 ? i : 0], n0 + xl, k0, kl, sb[i]) << i;
+          else B.load(bctx[SB::NCTX > 1 ? i : 0], n0 + xl, k0, kl, sb[i]);
+        }
       }
     };
 
@@ -562,7 +695,7 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
       // fp32, then doubles -- across the lane halves by a cross-lane move, across the WGM row waves through LDS (free: every
       // wave is past the K loop's last barrier), in a fixed order.  Rows beyond M hold exact zeros (their operand rows were
       // out of range) and add nothing.
-      if (E.stat != nullptr && kt0 == 0 && kt1 == ktiles) {
+      if (E.stat != nullptr && kt0 == 0 && kt1 == klen) {
         double* red = reinterpret_cast<double*>(smem);          // [WGM][BN][2]
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -597,20 +730,25 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
     // row-major outputs that fit 32-bit offsets take the fast path: interior tiles skip the per-element range checks
     // and every store is one v_add on a 32-bit offset against the scalar base (global_store_dword v, v, s[C]).
     const bool atomic = kchunks > 0;       // K-major cells (tuning mode, off by default): several cells share a tile
+    // where the tile's rows live: the whole output, or (position classes) the view of the tile's grid position
+    float* Cv = nullptr;
+    int mrow0 = m0, Mv = M;
+    if constexpr (HasSched<Epi>::value) { const auto v = E.view(m0); Cv = v.C; mrow0 = v.row0; Mv = v.M; }
+    else if constexpr (IsPlain<Epi>::value) Cv = E.C;
     bool fast = false;
-    if constexpr (IsPlain<Epi>::value) fast = E.cs == 1 && (long)M * E.ldc < (1L << 31) && m0 + BM <= M && n0 + BN <= N;
+    if constexpr (IsPlain<Epi>::value) fast = E.cs == 1 && (long)Mv * E.ldc < (1L << 31) && mrow0 + BM <= Mv && n0 + BN <= N;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn * (BN / WGN) + j * 32 + li_e;
         const float bv = (E.bias && n < N && kt0 == 0) ? E.bias[n] : 0.f;
-        const int mb = m0 + wm * (BM / WGM) + i * 32;
+        const int mb = mrow0 + wm * (BM / WGM) + i * 32;       // (row in the tile's view)
         if constexpr (IsPlain<Epi>::value) {
           if (fast) {
             const unsigned ld32 = (unsigned)E.ldc;
             const unsigned base = (unsigned)(mb + 4 * lh_e) * ld32 + (unsigned)n;
-            float* const Cb = E.C;
+            float* const Cb = Cv;
             if (atomic) {
 #pragma unroll
               for (int r = 0; r < 16; ++r) atomicAdd(Cb + (base + (unsigned)mfma32_row(r, 0) * ld32), acc[i][j][r] + bv);
@@ -630,8 +768,10 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = mb + mfma32_row(r, lh_e);
-          if (m < M && n < N) {
-            float* const p = E.ptr(m, n);
+          if (m < Mv && n < N) {
+            float* p;
+            if constexpr (HasSched<Epi>::value) p = Cv + (long)m * E.ldc + n;
+            else p = E.ptr(m, n);
             const float v = acc[i][j][r] + bv;
             if (atomic) atomicAdd(p, v);
             else if (E.mode == 0) *p = v;
@@ -748,13 +888,18 @@ __global__ void __launch_bounds__(256)
   const int sg = blockIdx.x * 4 + wave;
   const int tr = sg / STRIPS, strip = sg % STRIPS;
   if (tr >= rem_tiles) return;
-  const unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, Gu = (unsigned)G;
-  const unsigned it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  const unsigned Gu = (unsigned)G;
+  if constexpr (HasSched<Epi>::value) {            // position classes: tiles of different lengths, all of them in the pool
+    R = (unsigned)E.sched.total();
+    it0 = (unsigned)E.sched.base(tr);
+    it1 = it0 + (unsigned)E.sched.len(tr) - 1u;
+  }
   const int ga = (int)(((it0 + 1u) * Gu + R - 1u) / R) - 1, gb = (int)(((it1 + 1u) * Gu + R - 1u) / R) - 1;
   const int e0 = strip * 256 + lane * 4;
   const unsigned tile = (unsigned)full_rounds * Gu + (unsigned)tr;
   const int m = (int)(tile / (unsigned)ntn) * BM + e0 / BN, n0 = (int)(tile % (unsigned)ntn) * BN + e0 % BN;
-  if (m >= M) return;
+  if (!epi_live(E, m, M)) return;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   if (gb > ga) {
     const bool sparse = R < Gu;
@@ -797,22 +942,30 @@ __global__ void __launch_bounds__(256)
 // piece the first worker stored, writes the total back and keeps sum / sum of squares of its columns (fp32 over its BM / RG
 // rows, then doubles); the RG row groups meet in LDS in a fixed order.  Tiles that one worker finished by itself are skipped
 // (the kernel wrote their statistics).
-template <int BM, int BN>
+template <int BM, int BN, class Epi = EpiStore>
 __global__ void __launch_bounds__(256)
-    fixup_tile(const EpiStore E, const float* __restrict__ slab, const int M, const int N, const int ktiles, const long G,
+    fixup_tile(const Epi E, const float* __restrict__ slab, const int M, const int N, const int ktiles, const long G,
                const int full_rounds, const int rem_tiles, const int ntn) {
   constexpr int CQ = BN / 4, RG = 256 / CQ, RPT = BM / RG;
   static_assert(RPT % 4 == 0, "four rows in flight per thread");
   __shared__ double red[RG * BN * 2];
   const int tr = blockIdx.x;
-  const unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, Gu = (unsigned)G;
-  const unsigned it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  const unsigned Gu = (unsigned)G;
+  if constexpr (HasSched<Epi>::value) {
+    R = (unsigned)E.sched.total();
+    it0 = (unsigned)E.sched.base(tr);
+    it1 = it0 + (unsigned)E.sched.len(tr) - 1u;
+  }
   const int ga = (int)(((it0 + 1u) * Gu + R - 1u) / R) - 1, gb = (int)(((it1 + 1u) * Gu + R - 1u) / R) - 1;
   if (gb <= ga) return;                                  // block-uniform
   const bool sparse = R < Gu;
   const unsigned tile = (unsigned)full_rounds * Gu + (unsigned)tr;
   const int tm = (int)(tile / (unsigned)ntn);
   const int m0 = tm * BM, n0 = (int)(tile % (unsigned)ntn) * BN;
+  float* Cv = E.C;
+  int mrow0 = m0, Mv = M;
+  if constexpr (HasSched<Epi>::value) { const auto v = E.view(m0); Cv = v.C; mrow0 = v.row0; Mv = v.M; }
   const int cq = threadIdx.x % CQ, rg = threadIdx.x / CQ;
   const int n = n0 + cq * 4;
   float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -825,7 +978,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int row = rg + RG * (rr + u);
-        live[u] = m0 + row < M;
+        live[u] = mrow0 + row < Mv;
         sp[u] = slab + (long)(live[u] ? row : 0) * BN + cq * 4;
         tot[u] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
@@ -840,7 +993,7 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (!live[u]) continue;
-        float4* const cp = reinterpret_cast<float4*>(E.C + (long)(m0 + rg + RG * (rr + u)) * E.ldc + n);
+        float4* const cp = reinterpret_cast<float4*>(Cv + (long)(mrow0 + rg + RG * (rr + u)) * E.ldc + n);
         float4 o = *cp;
         o.x += tot[u].x; o.y += tot[u].y; o.z += tot[u].z; o.w += tot[u].w;
         *cp = o;
@@ -971,6 +1124,33 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e_in, int M, int
     else
       hipLaunchKernelGGL((fixup<BM, BN, Epi>), dim3(rt * (BM * BN / 256)), dim3(256), 0, s, e, slab, M, N, ktiles, G, fr, rt, cdiv(N, BN));
   }
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
+
+// Position-class product (ClassSched / EpiCls above): every tile is in the stream-K pool, tiles differ in length.  Needs the
+// scratch and a tile count that does not exceed the worker count; the caller falls back to launch() otherwise (returns
+// AVVAD_EINVAL without launching anything).  128x128 tiles, 8 waves, fp32.
+template <class AOp, class BOp>
+static inline int launch_cls(const AOp& a, const BOp& b, const EpiCls& e, int Mp, int N, hipStream_t s, float* slab) {
+  constexpr int BM = 128, BN = 128;
+  if (Mp <= 0 || N <= 0 || !slab) return AVVAD_EINVAL;
+  const AvvadTune& tn = avvad_tune();
+  const long ntiles = (long)cdiv(Mp, BM) * cdiv(N, BN);
+  const int cus = (tn.max_cus > 0 && tn.max_cus < NUM_CU) ? tn.max_cus : NUM_CU;
+  long G = (long)cus * 2;
+  if (G * BM * BN > (long)SLAB_FLOATS) G = (long)(SLAB_FLOATS / ((size_t)BM * BN));
+  const long R = e.sched.total();
+  if (ntiles > G || ntiles != (long)e.sched.Ho * e.sched.Wo * e.sched.tpc || R <= 0 || (double)R * (double)G >= 4.0e9) return AVVAD_EINVAL;
+  if (G > R / 4) G = R / 4 > 0 ? R / 4 : 1;
+  if (e.stat && (e.cs != 1 || (e.ldc & 3) || (N & 3) || (((uintptr_t)e.C) & 15) || (e.W & 3))) return AVVAD_EINVAL;
+  hipLaunchKernelGGL((kernel<BM, BN, true, 512, AOp, BOp, EpiCls, false>), dim3((int)G), dim3(512), 0, s, a, b, e, Mp, N, 0, 1, 0,
+                     (int)ntiles, 0, slab);
+  if (e.stat)
+    hipLaunchKernelGGL((fixup_tile<BM, BN, EpiCls>), dim3((int)ntiles), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0, (int)ntiles, cdiv(N, BN));
+  else
+    hipLaunchKernelGGL((fixup1<BM, BN, EpiCls>), dim3((int)ntiles * (BM * BN / 1024)), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0,
+                       (int)ntiles, cdiv(N, BN));
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

@@ -27,6 +27,7 @@ const OptName kOpts[] = {
     {"wn_dx", "AVVAD_WN_DX", &AvvadTune::wn_dx},
     {"bf16", "AVVAD_BF16", &AvvadTune::bf16},
     {"no_fused_stats", "AVVAD_NO_FUSED_STATS", &AvvadTune::no_fused_stats},
+    {"no_cls", "AVVAD_NO_CLS", &AvvadTune::no_cls},
     {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
 };
 int parse_opt(const char* name, const char* v) {

@@ -494,6 +494,46 @@ static inline int fwd_tile_rows(const Geom& g) {
   if (avvad_tune().bf16 == 1) return 128;                   // the bf16 engine's tiles (bgemm.h)
   return g.Co <= 64 && !avvad_tune().no_tall ? 256 : 128;
 }
+// ---- position classes (igemm.h): 3x3 / pad 1 convolutions whose tile count fits the stream-K pool skip the zero padding
+static inline bool cls_common(const Geom& g, float* slab) {
+  return avvad_tune().bf16 == 0 && !avvad_tune().no_cls && slab && g.KS == 3 && g.pad == 1 && g.N >= 128 && g.C % 32 == 0 &&
+         g.Co % 32 == 0 && g.Ho >= 2 && g.Wo >= 2 && avvad_tune().igemm_variant < 0 && !avvad_tune().no_buf &&
+         avvad_tune().no_streamk == 0;
+}
+static inline bool conv_fwd_cls_ok(const Geom& g, float* slab) {
+  if (!cls_common(g, slab) || g.Co % 4 || g.Co < 128) return false;
+  const long tiles = (long)g.Ho * g.Wo * cdiv(g.N, 128) * cdiv(g.Co, 128);
+  return tiles <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256) &&
+         fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf(9L * g.C * g.Co);
+}
+static inline bool conv_dgrad_cls_ok(const Geom& g, float* slab) {
+  if (!cls_common(g, slab) || g.stride != 1 || g.C % 4 || g.C < 128) return false;
+  const long tiles = (long)g.H * g.W * cdiv(g.N, 128) * cdiv(g.C, 128);
+  return tiles <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256) &&
+         fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && fits_buf(9L * g.C * g.Co);
+}
+static int conv_fwd_cls(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
+  const int NP = cdiv(g.N, 128) * 128, P = g.Ho * g.Wo;
+  const int lsh = ((g.Ho - 1) * g.stride - g.pad + 2 > g.H - 1) ? 1 : 0, lsw = ((g.Wo - 1) * g.stride - g.pad + 2 > g.W - 1) ? 1 : 0;
+  const igemm::ClassSched sc{g.Ho, g.Wo, (NP / 128) * cdiv(g.Co, 128), g.C / 32, 3, 1, lsh, 1, lsw};
+  convop::Im2colFwdCls a{x, g, NP, g.N, convop::div_magic(NP), sc};
+  convop::ColTapRowsCls b{wf, g.Co, g.Co, g.C, 3, NP, 0, convop::div_magic(NP), sc};
+  igemm::EpiCls e{y, (long)P * g.Co, nullptr, 0};
+  e.stat = stat; e.W = g.Co; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
+  return igemm::launch_cls(a, b, e, P * NP, g.Co, s, slab);
+}
+static int conv_dgrad_cls(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
+  const int NP = cdiv(g.N, 128) * 128, P = g.H * g.W;
+  const igemm::ClassSched sc{g.H, g.W, (NP / 128) * cdiv(g.C, 128), g.Co / 32, 3, 1, 1, 1, 1};
+  convop::Im2colDgradCls a{dy, g, NP, g.N, convop::div_magic(NP), sc};
+  convop::ColTapRowsCls b{wd, g.C, g.C, g.Co, 3, NP, 1, convop::div_magic(NP), sc};
+  igemm::EpiCls e{dx, (long)P * g.C, nullptr, accumulate ? 1 : 0};
+  e.W = g.C; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
+  return igemm::launch_cls(a, b, e, P * NP, g.C, s, slab);
+}
+// number of partial-sum chunks the forward of convolution g leaves in its `stat` buffer (one per M tile of its GEMM)
+static inline int fwd_stat_chunks(const Geom& g, float* slab);
+
 // stat: per-M-tile column sums / sums of squares of y (igemm::EpiStore::stat), or null
 template <bool BUF>
 static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
@@ -520,7 +560,16 @@ static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, 
   if (g.Co <= 64) return avvad_tune().no_tall ? igemm::launch<128, 64>(a, b, e, M, g.Co, K, 1, s, slab) : igemm::launch<256, 64>(a, b, e, M, g.Co, K, 1, s, slab);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, 1, s, slab);
 }
+static inline bool conv_fwd16_cls_ok(const Geom& g, float* slab);
+static inline int fwd_stat_chunks(const Geom& g, float* slab) {
+  if (avvad_tune().bf16 == 1)
+    return (g.C % 64 == 0 && g.Co % 64 == 0 && conv_fwd16_cls_ok(g, slab)) ? g.Ho * g.Wo * cdiv(g.N, 128) : cdiv((long)g.N * g.Ho * g.Wo, 128);
+  if (conv_fwd_cls_ok(g, slab)) return g.Ho * g.Wo * cdiv(g.N, 128);
+  const int rows = fwd_tile_rows(g);
+  return rows ? cdiv((long)g.N * g.Ho * g.Wo, rows) : 0;
+}
 static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat = nullptr) {
+  if (conv_fwd_cls_ok(g, slab)) return conv_fwd_cls(x, wf, y, g, s, slab, stat);
   const bool buf = fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.KS * g.KS * g.C * g.Co) && !avvad_tune().no_buf;
   return buf ? conv_fwd_t<true>(x, wf, y, g, s, slab, stat) : conv_fwd_t<false>(x, wf, y, g, s, slab, stat);
 }
@@ -568,6 +617,7 @@ static int conv_dgrad_t(const float* dy, const float* wd, float* dx, const Geom&
   return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s, slab);
 }
 static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
+  if (conv_dgrad_cls_ok(g, slab)) return conv_dgrad_cls(dy, wd, dx, g, accumulate, s, slab);
   const bool buf = fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && fits_buf((long)g.KS * g.KS * g.C * g.Co) && !avvad_tune().no_buf;
   return buf ? conv_dgrad_t<true>(dy, wd, dx, g, accumulate, s, slab) : conv_dgrad_t<false>(dy, wd, dx, g, accumulate, s, slab);
 }
@@ -618,8 +668,32 @@ static inline bool bf16_conv_ok(const Geom& g) {
   return g.C % 64 == 0 && g.Co % 64 == 0 && taps_fit(g) && fits_buf((long)g.N * g.H * g.W * g.C / 2) &&
          fits_buf((long)g.N * g.Ho * g.Wo * g.Co / 2) && fits_buf((long)g.KS * g.KS * g.C * g.Co / 2);
 }
+// position classes on the bf16 engine (the zero padding skipped: igemm.h); 64-channel chunks
+static inline bool cls16_common(const Geom& g, float* slab) {
+  return !avvad_tune().no_cls && slab && g.KS == 3 && g.pad == 1 && g.N >= 128 && g.Ho >= 2 && g.Wo >= 2 && avvad_tune().no_streamk == 0;
+}
+static inline bool conv_fwd16_cls_ok(const Geom& g, float* slab) {
+  if (!cls16_common(g, slab) || g.Co < 128) return false;
+  return (long)g.Ho * g.Wo * cdiv(g.N, 128) * cdiv(g.Co, 128) <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256);
+}
+static inline bool conv_dgrad16_cls_ok(const Geom& g, float* slab) {
+  if (!cls16_common(g, slab) || g.stride != 1 || g.C < 128) return false;
+  return (long)g.H * g.W * cdiv(g.N, 128) * cdiv(g.C, 128) <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256);
+}
 static int conv_fwd16(const float* x16, const float* wf16, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
   if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
+  if (conv_fwd16_cls_ok(g, slab)) {
+    const int NP = cdiv(g.N, 128) * 128, P = g.Ho * g.Wo;
+    const int lsh = ((g.Ho - 1) * g.stride - g.pad + 2 > g.H - 1) ? 1 : 0, lsw = ((g.Wo - 1) * g.stride - g.pad + 2 > g.W - 1) ? 1 : 0;
+    const igemm::ClassSched sc{g.Ho, g.Wo, (NP / 128) * cdiv(g.Co, 128), g.C / 64, 3, 1, lsh, 1, lsw};
+    Geom gp = g;
+    gp.C = g.C / 2;
+    convop::Im2colFwdCls a{x16, gp, NP, g.N, convop::div_magic(NP), sc};
+    bgemm::RowPairsCls b{wf16, 9 * g.C / 2, g.Co, 9, 3, NP, 0, convop::div_magic(NP), sc};
+    igemm::EpiCls e{y, (long)P * g.Co, nullptr, 0};
+    e.stat = stat; e.W = g.Co; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
+    return bgemm::launch_cls(a, b, e, P * NP, g.Co, s, slab);
+  }
   const int M = g.N * g.Ho * g.Wo, T = g.KS * g.KS, Kp = T * g.C / 2;
   Geom gp = g;
   gp.C = g.C / 2;                                            // the gather addresses bf16 PAIRS
@@ -663,6 +737,15 @@ static int conv_dgrad16(const float* dy16, const float* wd16, float* dx, const G
       }
     return AVVAD_OK;
   }
+  if (conv_dgrad16_cls_ok(g, slab)) {
+    const int NP = cdiv(g.N, 128) * 128, P = g.H * g.W;
+    const igemm::ClassSched sc{g.H, g.W, (NP / 128) * cdiv(g.C, 128), g.Co / 64, 3, 1, 1, 1, 1};
+    convop::Im2colDgradCls a{dy16, gp, NP, g.N, convop::div_magic(NP), sc};
+    bgemm::RowPairsCls b{wd16, Kp, g.C, 9, 3, NP, 1, convop::div_magic(NP), sc};
+    igemm::EpiCls e{dx, (long)P * g.C, nullptr, accumulate ? 1 : 0};
+    e.W = g.C; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
+    return bgemm::launch_cls(a, b, e, P * NP, g.C, s, slab);
+  }
   convop::Im2colDgrad<true> a{dy16, gp, M, convop::tap_div(T, g.KS)};
   bgemm::RowPairs b{wd16, Kp, g.C, Kp};
   igemm::EpiStore e{dx, g.C, nullptr, accumulate ? 1 : 0};
@@ -701,8 +784,8 @@ static StatCtx stat_ctx(Plan* p, float* ws, long M, int C) {
 static double* fused_stat(Plan* p, float* ws, int i, const avvad_trunk_desc* d) {
   const int rows = fwd_tile_rows(p->geom[i]);
   if (!d->training || rows == 0 || avvad_tune().no_fused_stats) return nullptr;
-  const long M = (long)p->geom[i].N * p->geom[i].Ho * p->geom[i].Wo;
-  if ((long)cdiv(M, rows) * p->conv[i].cout > (long)STAT_CHUNKS * MAXC) return nullptr;      // the partial-sum buffer's size
+  const long chunks = fwd_stat_chunks(p->geom[i], ws + p->slab);
+  if (chunks * p->conv[i].cout > (long)STAT_CHUNKS * MAXC) return nullptr;      // the partial-sum buffer's size
   return reinterpret_cast<double*>(ws + p->part);
 }
 static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, const avvad_trunk_params* prm,
@@ -710,7 +793,7 @@ static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, cons
   const int C = p->conv[i].cout;
   StatCtx sc = stat_ctx(p, ws, M, C);
   if (fused_stat(p, ws, i, d)) {
-    sc.nchunk = cdiv(M, fwd_tile_rows(p->geom[i]));     // written by the convolution's epilogue / fix-up, one chunk per M tile
+    sc.nchunk = fwd_stat_chunks(p->geom[i], ws + p->slab);   // one chunk per M tile of the conv's GEMM
   } else if (d->training) {
     hipLaunchKernelGGL(col_reduce<0>, dim3(sc.nchunk), dim3(256), 0, s, craw, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, M, C, sc.rows_per_chunk, sc.part);

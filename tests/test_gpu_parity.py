@@ -842,14 +842,16 @@ def test_bf16_convolutions_vs_rounded_operands(N, H, W, C, Co, KS, stride, pad, 
 
 @pytest.mark.parametrize("N,H,W,C,Co,KS,stride,pad", [(3, 17, 17, 64, 64, 3, 1, 1), (2, 17, 17, 64, 128, 3, 2, 1), (5, 9, 9, 128, 128, 3, 1, 1),
                                                       (2, 17, 17, 64, 128, 1, 2, 0), (4, 3, 3, 512, 512, 3, 1, 1), (700, 9, 9, 128, 128, 3, 1, 1),
-                                                      (300, 5, 5, 256, 256, 3, 1, 1), (96, 9, 9, 128, 256, 3, 2, 1), (40, 17, 17, 64, 64, 3, 1, 1)])
+                                                      (300, 5, 5, 256, 256, 3, 1, 1), (96, 9, 9, 128, 256, 3, 2, 1), (40, 17, 17, 64, 64, 3, 1, 1),
+                                                      (130, 3, 3, 512, 512, 3, 1, 1), (256, 9, 9, 128, 256, 3, 2, 1), (200, 5, 5, 256, 512, 3, 2, 1)])
 def test_bf16_data_path_convolutions(N, H, W, C, Co, KS, stride, pad):
     """The bf16 DATA PATH's convolutions (csrc/bgemm.h; what the trunk runs under option bf16 = 1): operands are bf16 in
     memory -- NHWC bf16 activations / output gradients, K-contiguous bf16 weight packs -- staged with 16-byte loads, the
     weight gradient's operands transposed by ds_read_b64_tr_b16, fp32 accumulation and fp32 results.  Exact check as above:
     F.conv2d in fp32 on the bf16 values has the very same products; only the fp32 summation order differs.  A wrong lane /
     k-slot / chunk in the LDS images, the transposed reads or the weight packs is an O(1) error.  Covers whole-tile rounds,
-    stream-K rounds with the ordered fix-up (N = 700, 300), the four stride-2 parity classes and the 1x1 downsample."""
+    stream-K rounds with the ordered fix-up (N = 700, 300), the four stride-2 parity classes, the 1x1 downsample, and -- from
+    128 images up, where the tile count fits the stream-K pool -- the position-class schedule that skips the zero padding."""
     import ctypes as Ct
     import torch.nn.functional as F
     from avvad import _lib as L, ops
@@ -1402,6 +1404,52 @@ def test_bf16_benched_model_ragged_logits_vs_fp32_oracle(lib_options):
     assert float((y16.cpu() - ref).abs().max()) > 1e-6      # the option really changed the arithmetic
     for b, n in enumerate(lens):                             # padded steps: the Linear bias, exactly, in either arithmetic
         assert torch.equal(y16[b, n:], y32[b, n:])
+
+
+@pytest.mark.parametrize("N,H,W,C,Co,stride", [(200, 5, 5, 256, 256, 1), (130, 3, 3, 512, 512, 1), (256, 9, 9, 128, 256, 2),
+                                               (128, 5, 5, 256, 512, 2), (300, 3, 3, 256, 128, 1), (1024, 3, 3, 512, 512, 1)])
+def test_conv2d_position_classes_skip_the_zero_padding(N, H, W, C, Co, stride, lib_options):
+    """3x3 / pad 1 convolutions whose tile count fits the stream-K pool run position-major (igemm.h "position classes"): a
+    tile's rows share one grid position, its K loop walks only the taps that fall inside the image -- on a 3x3 grid 40 % of
+    the products are multiplications by the zero padding.  Forward and data gradient against torch's conv2d (same bound as
+    the dense schedule), with image counts that are not whole tiles (padded class rows), both strides; the skipped products
+    are exact zeros, so the dense schedule (option no_cls) must agree to the last bits of the fp32 summation order."""
+    import ctypes as Ct
+    import torch.nn.functional as F
+    from avvad import _lib as L, ops
+    rng = np.random.RandomState(N + H * 7 + C)
+    x = T(rng.normal(size=(N, C, H, W)).astype(np.float32)).requires_grad_(True)
+    w = T((rng.normal(size=(Co, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32))
+    torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    y = F.conv2d(x, w, None, stride, 1)
+    gy = T(rng.normal(size=tuple(y.shape)).astype(np.float32))
+    y.backward(gy)
+    lib = L.lib()
+    st = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(N, H, W, C, Co, 3, stride, 1)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    wf = torch.empty(9 * C * Co, device=DEV)
+    wdg = torch.empty(9 * C * Co, device=DEV)
+    L.check(lib.avvad_conv2d_pack_weights(L.ptr(w.to(DEV)), L.ptr(wf), L.ptr(wdg), Ct.byref(d), st), "pack")
+    ews = ops.engine_ws(DEV)
+    gyd = gy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    outs = {}
+    for no_cls in (0, 1):
+        lib_options("no_cls", no_cls)
+        yd = torch.full((N, y.shape[2], y.shape[3], Co), float("nan"), device=DEV)
+        L.check(lib.avvad_conv2d_fwd(L.ptr(xd), L.ptr(wf), L.ptr(yd), Ct.byref(d), L.ptr(ews), ews.numel() * 4, st), "fwd")
+        tag = "conv %dx%dx%dx%d->%d s%d %s" % (N, H, W, C, Co, stride, "dense" if no_cls else "classes")
+        _report(tag + " fwd", yd.permute(0, 3, 1, 2), y, 2e-5, 2e-5)
+        dx = torch.full((N, H, W, C), float("nan"), device=DEV)
+        L.check(lib.avvad_conv2d_dgrad(L.ptr(gyd), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 0, L.ptr(ews), ews.numel() * 4, st), "dgrad")
+        _report(tag + " dgrad", dx.permute(0, 3, 1, 2), x.grad, 2e-5, 2e-5)
+        L.check(lib.avvad_conv2d_dgrad(L.ptr(gyd), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 1, L.ptr(ews), ews.numel() * 4, st), "dgrad +=")
+        _report(tag + " dgrad accumulate", dx.permute(0, 3, 1, 2), 2 * x.grad, 4e-5, 4e-5)
+        outs[no_cls] = (yd, dx)
+        yd2 = torch.empty_like(yd)
+        L.check(lib.avvad_conv2d_fwd(L.ptr(xd), L.ptr(wf), L.ptr(yd2), Ct.byref(d), L.ptr(ews), ews.numel() * 4, st), "fwd")
+        assert torch.equal(yd, yd2)                              # run to run: the same bits
+    assert _max_rel(outs[0][0], outs[1][0]) < 2e-6 and _max_rel(outs[0][1], outs[1][1]) < 4e-6
 
 
 def test_conv2d_refuses_kernels_beyond_the_tap_mask():
