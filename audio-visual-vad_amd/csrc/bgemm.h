@@ -179,9 +179,8 @@ __global__ void __launch_bounds__(256, 2)
       else bctx[i] = B.prep(bx0 + xl);
     }
 
-    ClassTile atile, btile;
-    if constexpr (HasTile<AOp>::value) atile = A.tile(m0);
-    if constexpr (HasTile<BOp>::value) btile = B.tile(m0);
+    const typename igemm::TileOf<AOp>::type atile = igemm::TileOf<AOp>::get(A, m0);
+    const typename igemm::TileOf<BOp>::type btile = igemm::TileOf<BOp>::get(B, m0);
     (void)atile; (void)btile;
     float sa[NVA][4], sb[NVB][4];
     auto gload = [&](int kt) {
@@ -420,8 +419,8 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e, int M, int N,
 }
 
 // position-class product on the bf16 engine (igemm::launch_cls is the fp32 twin): 128x128 KK tiles
-template <class AOp, class BOp>
-static inline int launch_cls(const AOp& a, const BOp& b, const EpiCls& e, int Mp, int N, hipStream_t s, float* slab) {
+template <bool MM, class AOp, class BOp, class Epi>
+static inline int launch_cls(const AOp& a, const BOp& b, const Epi& e, int Mp, int N, hipStream_t s, float* slab) {
   constexpr int BM = 128, BN = 128;
   if (Mp <= 0 || N <= 0 || !slab) return AVVAD_EINVAL;
   const AvvadTune& tn = avvad_tune();
@@ -430,15 +429,24 @@ static inline int launch_cls(const AOp& a, const BOp& b, const EpiCls& e, int Mp
   long G = (long)cus * 2;
   if (G * BM * BN > (long)igemm::SLAB_FLOATS) G = (long)(igemm::SLAB_FLOATS / ((size_t)BM * BN));
   const long R = e.sched.total();
-  if (ntiles > G || ntiles != (long)e.sched.Ho * e.sched.Wo * e.sched.tpc || R <= 0 || (double)R * (double)G >= 4.0e9) return AVVAD_EINVAL;
+  if (ntiles > G || R <= 0 || (double)R * (double)G >= 4.0e9) return AVVAD_EINVAL;
   if (G > R / 4) G = R / 4 > 0 ? R / 4 : 1;
-  if (e.stat && (e.cs != 1 || (e.ldc & 3) || (N & 3) || (((uintptr_t)e.C) & 15) || (e.W & 3))) return AVVAD_EINVAL;
-  hipLaunchKernelGGL((kernel<BM, BN, false, AOp, BOp, EpiCls>), dim3((int)G), dim3(256), 0, s, a, b, e, Mp, N, 1, 0, (int)ntiles, slab);
-  if (e.stat)
-    hipLaunchKernelGGL((igemm::fixup_tile<BM, BN, EpiCls>), dim3((int)ntiles), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0, (int)ntiles, cdiv(N, BN));
-  else
-    hipLaunchKernelGGL((igemm::fixup1<BM, BN, EpiCls>), dim3((int)ntiles * (BM * BN / 1024)), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0,
+  bool stat = false;
+  if constexpr (HasStat<Epi>::value) {
+    stat = e.stat != nullptr;
+    if (stat && (e.cs != 1 || (e.ldc & 3) || (N & 3) || (((uintptr_t)e.C) & 15) || (e.W & 3))) return AVVAD_EINVAL;
+  }
+  hipLaunchKernelGGL((kernel<BM, BN, MM, AOp, BOp, Epi>), dim3((int)G), dim3(256), 0, s, a, b, e, Mp, N, 1, 0, (int)ntiles, slab);
+  if (stat) {
+    if constexpr (HasStat<Epi>::value)
+      hipLaunchKernelGGL((igemm::fixup_tile<BM, BN, Epi>), dim3((int)ntiles), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0, (int)ntiles, cdiv(N, BN));
+  } else if ((G + ntiles - 1) / ntiles <= 6) {
+    hipLaunchKernelGGL((igemm::fixup1<BM, BN, Epi>), dim3((int)ntiles * (BM * BN / 1024)), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0,
                        (int)ntiles, cdiv(N, BN));
+  } else {
+    hipLaunchKernelGGL((igemm::fixup<BM, BN, Epi>), dim3((int)ntiles * (BM * BN / 256)), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0,
+                       (int)ntiles, cdiv(N, BN));
+  }
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

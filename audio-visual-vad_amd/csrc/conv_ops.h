@@ -398,6 +398,59 @@ struct ColTapRowsCls {
   }
 };
 
+// ---- weight gradient by taps (igemm.h TapSched): A[m = tap * Cu + c][k' = p * NP + n] = x[n, ho s - 1 + kh, wo s - 1 + kw, c],
+// B[k'][co] = dy[n, ho, wo, co]; only the grid positions at which the tile's tap is inside the image are walked.
+// Units: Cu / X count operand ELEMENTS (fp32 engine: channels; bf16 engine: channel pairs); Ct = REAL rows per tap (what the
+// kernel's m0 counts).  Both operands are contiguous along M / N (16-byte fetches of 4 elements).
+struct WgradXTap {
+  static constexpr bool KCONTIG = false;
+  static constexpr int VEC = 4;
+  struct Ctx { unsigned boff; int ok; };
+  const float* x;
+  Geom g;                       // g.C in operand elements
+  int M, Ct, rows;              // M in operand elements; Ct real rows per tap; rows = images
+  unsigned mg_Cu;               // magic of g.C
+  igemm::TapSched sc;
+  __device__ __forceinline__ Ctx prep(int m) const {
+    Ctx c;
+    c.ok = m < M;
+    c.boff = (unsigned)(m - fast_div(m, mg_Cu) * g.C) * 4u;             // the channel (pair) inside its tap
+    return c;
+  }
+  __device__ __forceinline__ igemm::TapTile tile(int m0) const { return igemm::tap_tile(sc, m0 / Ct); }
+  __device__ __forceinline__ void load(const Ctx& c, const igemm::TapTile& t, int, int k0, int kin, float* v) const {
+    int ho, wo, n0;
+    igemm::tap_pos(t, k0, ho, wo, n0);
+    const int hi = ho * g.stride - g.pad + t.kh, wi = wo * g.stride - g.pad + t.kw;       // inside the image by construction
+    const unsigned soff = (unsigned)(hi * g.W + wi) * (unsigned)g.C * 4u;                 // scalar
+    const int n = n0 + kin;
+    fetch4<true>(x, (c.ok && n < rows) ? (unsigned)n * (unsigned)(g.H * g.W * g.C) * 4u + c.boff + soff : INVALID_OFF(true), v);
+  }
+};
+struct ColDyTap {
+  static constexpr bool KCONTIG = false;
+  static constexpr int VEC = 4;
+  struct Ctx { unsigned boff; int ok; };
+  const float* dy;
+  Geom g;                       // g.Co in operand elements
+  int X, Ct, rows;
+  igemm::TapSched sc;
+  __device__ __forceinline__ Ctx prep(int x) const {
+    Ctx c;
+    c.ok = x < X;
+    c.boff = (unsigned)x * 4u;
+    return c;
+  }
+  __device__ __forceinline__ igemm::TapTile tile(int m0) const { return igemm::tap_tile(sc, m0 / Ct); }
+  __device__ __forceinline__ void load(const Ctx& c, const igemm::TapTile& t, int, int k0, int kin, float* v) const {
+    int ho, wo, n0;
+    igemm::tap_pos(t, k0, ho, wo, n0);
+    const unsigned soff = (unsigned)(ho * g.Wo + wo) * (unsigned)g.Co * 4u;
+    const int n = n0 + kin;
+    fetch4<true>(dy, (c.ok && n < rows) ? (unsigned)n * (unsigned)(g.Ho * g.Wo * g.Co) * 4u + c.boff + soff : INVALID_OFF(true), v);
+  }
+};
+
 // ---- stem (C = 1): scalar gathers
 struct StemFwd {  // rows = output pixels, K = KS*KS (49), element = x[n, ho*2-3+kh, wo*2-3+kw]
   static constexpr bool KCONTIG = true;

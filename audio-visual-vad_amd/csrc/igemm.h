@@ -143,6 +143,87 @@ struct EpiCls {
     return C + (long)p * W + (long)(m - p * NP) * ldc + n;
   }
 };
+// The WEIGHT gradient's twin: C[(tap, c)][co] = sum over output pixels.  Rows are tap-major (a 128-row tile = one tap x 128
+// channels = rows of the packed gradient as they are), K runs over the pixels in the same position-major order k' = p * NP + n,
+// and a tile's K loop walks only the grid positions at which ITS tap falls inside the image: nh(kh) x nw(kw) positions of
+// NP / 32 K tiles each (tap (0, 0) of a 3x3 grid sees 4 of the 9 positions).
+struct TapSched {
+  int Ho, Wo, tpt, kpp;           // tiles per tap (channel tiles x N tiles); K tiles per grid position (NP / 32)
+  int KS, fsh, lsh, fsw, lsw;     // tap row kh = 0 misses the first fsh grid rows, kh = KS - 1 the last lsh (same for columns)
+  __host__ __device__ int nh(int kh) const { return Ho - (kh == 0 ? fsh : 0) - (kh == KS - 1 ? lsh : 0); }
+  __host__ __device__ int nw(int kw) const { return Wo - (kw == 0 ? fsw : 0) - (kw == KS - 1 ? lsw : 0); }
+  __host__ __device__ int len_tap(int tap) const { const int kh = tap / KS; return nh(kh) * nw(tap - kh * KS) * kpp; }
+  __host__ __device__ int len(int tile) const { return len_tap(tile / tpt); }
+  __host__ __device__ long base(int tile) const {
+    const int tap = tile / tpt;
+    long b = 0;
+    for (int q = 0; q < tap; ++q) b += (long)len_tap(q) * tpt;
+    return b + (long)(tile - tap * tpt) * len_tap(tap);
+  }
+  __host__ __device__ long total() const { return base(KS * KS * tpt); }
+  __device__ void locate(long it, int& tile, int& kt, int& klen) const {
+    int tap = 0;
+    long b = 0;
+    for (; tap + 1 < KS * KS; ++tap) {
+      const long l = (long)len_tap(tap) * tpt;
+      if (it < b + l) break;
+      b += l;
+    }
+    klen = len_tap(tap);
+    const int r = (int)((it - b) / klen);
+    kt = (int)(it - b - (long)r * klen);
+    tile = tap * tpt + r;
+  }
+};
+struct TapTile {
+  int kh, kw, h_lo, w_lo, rowlen, kpp;    // rowlen: K tiles per live grid row = nw(kw) * kpp
+  unsigned mg_rowlen, mg_kpp;
+};
+__device__ __forceinline__ TapTile tap_tile(const TapSched& s, int tap) {
+  TapTile t;
+  t.kh = tap / s.KS;
+  t.kw = tap - t.kh * s.KS;
+  t.h_lo = t.kh == 0 ? s.fsh : 0;
+  t.w_lo = t.kw == 0 ? s.fsw : 0;
+  t.kpp = s.kpp;
+  t.rowlen = s.nw(t.kw) * s.kpp;
+  t.mg_rowlen = dev_magic(t.rowlen);
+  t.mg_kpp = dev_magic(s.kpp);
+  return t;
+}
+// K tile q of a tap tile -> grid position (ho, wo) and first image n0 of its 32 pixels (all scalar)
+__device__ __forceinline__ void tap_pos(const TapTile& t, int k0, int& ho, int& wo, int& n0) {
+  const int q = k0 >> 5, j = dev_div(q, t.mg_rowlen), r = q - j * t.rowlen, pw = dev_div(r, t.mg_kpp);
+  ho = t.h_lo + j;
+  wo = t.w_lo + pw;
+  n0 = (r - pw * t.kpp) * 32;
+}
+struct EpiTap {      // plain [M][ldc] output (the packed weight gradient) + the schedule
+  static constexpr bool PLAIN = true;
+  float* C;
+  long ldc;
+  const float* bias;   // unused (null)
+  int mode;
+  int cs = 1;
+  int Mrows = 0;
+  TapSched sched;
+  struct View { float* C; int row0, M; };
+  __device__ __forceinline__ View view(int m0) const { return View{C, m0, Mrows}; }
+  __device__ __forceinline__ bool live(int) const { return true; }
+  __device__ __forceinline__ float* ptr(int m, int n) const { return C + (long)m * ldc + n; }
+};
+// what a functor's tile() hook returns (nothing for ordinary operands)
+struct NoTile {};
+template <class Op, class = void>
+struct TileOf {
+  typedef NoTile type;
+  __device__ static __forceinline__ type get(const Op&, int) { return NoTile(); }
+};
+template <class Op>
+struct TileOf<Op, std::void_t<decltype(&Op::tile)>> {
+  typedef decltype(std::declval<const Op&>().tile(0)) type;
+  __device__ static __forceinline__ type get(const Op& o, int m0) { return o.tile(m0); }
+};
 template <class Epi, class = void>
 struct HasSched : std::false_type {};
 template <class Epi>
@@ -512,9 +593,8 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
     }
 
     // position-class operands: what the tile's class means for its K loop (live taps), wave-uniform
-    ClassTile atile, btile;
-    if constexpr (HasTile<AOp>::value) atile = A.tile(m0);
-    if constexpr (HasTile<BOp>::value) btile = B.tile(m0);
+    const typename TileOf<AOp>::type atile = TileOf<AOp>::get(A, m0);
+    const typename TileOf<BOp>::type btile = TileOf<BOp>::get(B, m0);
     (void)atile; (void)btile;
 
     float sa[SA::NV][SA::VEC], sb[SB::NV][SB::VEC];
@@ -811,8 +891,13 @@ __global__ void __launch_bounds__(256)
   // worker of iteration it: shares are [g*R/G, (g+1)*R/G)  ->  g = ceil((it+1)*G/R) - 1.  All of this is block-uniform and
   // in 32 bits (the host launches this kernel only when R * G < 2^32: a 64-bit software division per thread and slab was
   // most of this kernel's time in its first version).
-  const unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, Gu = (unsigned)G;
-  const unsigned it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  unsigned R = (unsigned)rem_tiles * (unsigned)ktiles, it0 = (unsigned)tr * (unsigned)ktiles, it1 = it0 + (unsigned)ktiles - 1u;
+  const unsigned Gu = (unsigned)G;
+  if constexpr (HasSched<Epi>::value) {            // tiles of different lengths, all of them in the pool
+    R = (unsigned)E.sched.total();
+    it0 = (unsigned)E.sched.base(tr);
+    it1 = it0 + (unsigned)E.sched.len(tr) - 1u;
+  }
   const int ga = (int)(((it0 + 1u) * Gu + R - 1u) / R) - 1, gb = (int)(((it1 + 1u) * Gu + R - 1u) / R) - 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int e0 = strip * 256 + lane * 4;                 // tile-local element (row-major [BM][BN]) of this lane's float4
@@ -821,7 +906,7 @@ __global__ void __launch_bounds__(256)
       if (E.active && wave == 0) {
         const unsigned tile_u = (unsigned)full_rounds * Gu + (unsigned)tr;
         const int mu = (int)(tile_u / (unsigned)ntn) * BM + e0 / BN, nu = (int)(tile_u % (unsigned)ntn) * BN + e0 % BN;
-        if (mu < M) {
+        if (epi_live(E, mu, M)) {
           float v[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int e = 0; e < 4; ++e)
@@ -857,7 +942,7 @@ __global__ void __launch_bounds__(256)
   for (int w = 0; w < 3; ++w) { const float4 p = part[w][lane]; sum.x += p.x; sum.y += p.y; sum.z += p.z; sum.w += p.w; }
   const unsigned tile = (unsigned)full_rounds * Gu + (unsigned)tr;
   const int m = (int)(tile / (unsigned)ntn) * BM + e0 / BN, n0 = (int)(tile % (unsigned)ntn) * BN + e0 % BN;
-  if (m >= M) return;
+  if (!epi_live(E, m, M)) return;
   const float sv[4] = {sum.x, sum.y, sum.z, sum.w};
   if constexpr (HasFinish<Epi>::value) {
     if (E.active) {
@@ -1131,8 +1216,8 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e_in, int M, int
 // Position-class product (ClassSched / EpiCls above): every tile is in the stream-K pool, tiles differ in length.  Needs the
 // scratch and a tile count that does not exceed the worker count; the caller falls back to launch() otherwise (returns
 // AVVAD_EINVAL without launching anything).  128x128 tiles, 8 waves, fp32.
-template <class AOp, class BOp>
-static inline int launch_cls(const AOp& a, const BOp& b, const EpiCls& e, int Mp, int N, hipStream_t s, float* slab) {
+template <class AOp, class BOp, class Epi>
+static inline int launch_cls(const AOp& a, const BOp& b, const Epi& e, int Mp, int N, hipStream_t s, float* slab) {
   constexpr int BM = 128, BN = 128;
   if (Mp <= 0 || N <= 0 || !slab) return AVVAD_EINVAL;
   const AvvadTune& tn = avvad_tune();
@@ -1141,16 +1226,25 @@ static inline int launch_cls(const AOp& a, const BOp& b, const EpiCls& e, int Mp
   long G = (long)cus * 2;
   if (G * BM * BN > (long)SLAB_FLOATS) G = (long)(SLAB_FLOATS / ((size_t)BM * BN));
   const long R = e.sched.total();
-  if (ntiles > G || ntiles != (long)e.sched.Ho * e.sched.Wo * e.sched.tpc || R <= 0 || (double)R * (double)G >= 4.0e9) return AVVAD_EINVAL;
+  if (ntiles > G || R <= 0 || (double)R * (double)G >= 4.0e9) return AVVAD_EINVAL;
   if (G > R / 4) G = R / 4 > 0 ? R / 4 : 1;
-  if (e.stat && (e.cs != 1 || (e.ldc & 3) || (N & 3) || (((uintptr_t)e.C) & 15) || (e.W & 3))) return AVVAD_EINVAL;
-  hipLaunchKernelGGL((kernel<BM, BN, true, 512, AOp, BOp, EpiCls, false>), dim3((int)G), dim3(512), 0, s, a, b, e, Mp, N, 0, 1, 0,
+  bool stat = false;
+  if constexpr (HasStat<Epi>::value) {
+    stat = e.stat != nullptr;
+    if (stat && (e.cs != 1 || (e.ldc & 3) || (N & 3) || (((uintptr_t)e.C) & 15) || (e.W & 3))) return AVVAD_EINVAL;
+  }
+  hipLaunchKernelGGL((kernel<BM, BN, true, 512, AOp, BOp, Epi, false>), dim3((int)G), dim3(512), 0, s, a, b, e, Mp, N, 0, 1, 0,
                      (int)ntiles, 0, slab);
-  if (e.stat)
-    hipLaunchKernelGGL((fixup_tile<BM, BN, EpiCls>), dim3((int)ntiles), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0, (int)ntiles, cdiv(N, BN));
-  else
-    hipLaunchKernelGGL((fixup1<BM, BN, EpiCls>), dim3((int)ntiles * (BM * BN / 1024)), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0,
+  if (stat) {
+    if constexpr (HasStat<Epi>::value)
+      hipLaunchKernelGGL((fixup_tile<BM, BN, Epi>), dim3((int)ntiles), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0, (int)ntiles, cdiv(N, BN));
+  } else if ((G + ntiles - 1) / ntiles <= 6) {
+    hipLaunchKernelGGL((fixup1<BM, BN, Epi>), dim3((int)ntiles * (BM * BN / 1024)), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0,
                        (int)ntiles, cdiv(N, BN));
+  } else {
+    hipLaunchKernelGGL((fixup<BM, BN, Epi>), dim3((int)ntiles * (BM * BN / 256)), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0, (int)ntiles,
+                       cdiv(N, BN));
+  }
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }

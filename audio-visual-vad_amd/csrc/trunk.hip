@@ -654,7 +654,28 @@ static int conv_wgrad_t(const float* x, const float* dy, float* pk, const Geom& 
   if (small) return igemm::launch<128, 64>(a, b, e, M, g.Co, K, split, s, slab);
   return igemm::launch<128, 128>(a, b, e, M, g.Co, K, split, s, slab);
 }
+// weight gradient by taps (igemm.h TapSched): only the grid positions at which a tap is inside the image are contracted
+static inline bool conv_wgrad_tap_ok(const Geom& g, float* slab) {
+  if (!cls_common(g, slab) || g.C % 128 || g.Co % 4 || g.Co < 128) return false;
+  return 9L * (g.C / 128) * cdiv(g.Co, 128) <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256) &&
+         fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.N * g.Ho * g.Wo * g.Co);
+}
+static inline igemm::TapSched tap_sched(const Geom& g, int tiles_per_tap) {
+  const int NP = cdiv(g.N, 128) * 128;
+  const int lsh = ((g.Ho - 1) * g.stride - g.pad + 2 > g.H - 1) ? 1 : 0, lsw = ((g.Wo - 1) * g.stride - g.pad + 2 > g.W - 1) ? 1 : 0;
+  return igemm::TapSched{g.Ho, g.Wo, tiles_per_tap, NP / 32, 3, 1, lsh, 1, lsw};
+}
+static int conv_wgrad_tap(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s, float* slab) {
+  const int M = 9 * g.C;
+  const igemm::TapSched sc = tap_sched(g, (g.C / 128) * cdiv(g.Co, 128));
+  convop::WgradXTap a{x, g, M, g.C, g.N, convop::div_magic(g.C), sc};
+  convop::ColDyTap b{dy, g, g.Co, g.C, g.N, sc};
+  igemm::EpiTap e{pk, g.Co, nullptr, 0};
+  e.Mrows = M; e.sched = sc;
+  return igemm::launch_cls(a, b, e, M, g.Co, s, slab);
+}
 static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s, float* slab) {
+  if (conv_wgrad_tap_ok(g, slab)) return conv_wgrad_tap(x, dy, pk, g, s, slab);
   const bool buf = g.C > 1 && fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && !avvad_tune().no_buf;
   return buf ? conv_wgrad_t<true>(x, dy, pk, g, s, slab) : conv_wgrad_t<false>(x, dy, pk, g, s, slab);
 }
@@ -692,7 +713,7 @@ static int conv_fwd16(const float* x16, const float* wf16, float* y, const Geom&
     bgemm::RowPairsCls b{wf16, 9 * g.C / 2, g.Co, 9, 3, NP, 0, convop::div_magic(NP), sc};
     igemm::EpiCls e{y, (long)P * g.Co, nullptr, 0};
     e.stat = stat; e.W = g.Co; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
-    return bgemm::launch_cls(a, b, e, P * NP, g.Co, s, slab);
+    return bgemm::launch_cls<false>(a, b, e, P * NP, g.Co, s, slab);
   }
   const int M = g.N * g.Ho * g.Wo, T = g.KS * g.KS, Kp = T * g.C / 2;
   Geom gp = g;
@@ -744,7 +765,7 @@ static int conv_dgrad16(const float* dy16, const float* wd16, float* dx, const G
     bgemm::RowPairsCls b{wd16, Kp, g.C, 9, 3, NP, 1, convop::div_magic(NP), sc};
     igemm::EpiCls e{dx, (long)P * g.C, nullptr, accumulate ? 1 : 0};
     e.W = g.C; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
-    return bgemm::launch_cls(a, b, e, P * NP, g.C, s, slab);
+    return bgemm::launch_cls<false>(a, b, e, P * NP, g.C, s, slab);
   }
   convop::Im2colDgrad<true> a{dy16, gp, M, convop::tap_div(T, g.KS)};
   bgemm::RowPairs b{wd16, Kp, g.C, Kp};
@@ -756,6 +777,17 @@ static int conv_wgrad16(const float* x16, const float* dy16, float* pk, const Ge
   if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
   const int T = g.KS * g.KS, M = T * g.C, K = g.N * g.Ho * g.Wo;
   if ((unsigned long)(K + bgemm::BKU) * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
+  if (cls16_common(g, slab) && g.C % 128 == 0 && g.Co >= 128 &&
+      9L * (g.C / 128) * cdiv(g.Co, 128) <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256)) {
+    const igemm::TapSched sc = tap_sched(g, (g.C / 128) * cdiv(g.Co, 128));
+    Geom gq = g;
+    gq.C = g.C / 2; gq.Co = g.Co / 2;                        // operand elements are bf16 pairs
+    convop::WgradXTap a{x16, gq, M / 2, g.C, g.N, convop::div_magic(g.C / 2), sc};
+    convop::ColDyTap b{dy16, gq, g.Co / 2, g.C, g.N, sc};
+    igemm::EpiTap e{pk, g.Co, nullptr, 0};
+    e.Mrows = M; e.sched = sc;
+    return bgemm::launch_cls<true>(a, b, e, M, g.Co, s, slab);
+  }
   Geom gp = g;
   gp.C = g.C / 2;
   convop::WgradX<true> a{x16, gp, M / 2, K, convop::div_magic(g.Ho * g.Wo), convop::div_magic(g.Wo)};

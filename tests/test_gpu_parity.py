@@ -1411,8 +1411,9 @@ def test_bf16_benched_model_ragged_logits_vs_fp32_oracle(lib_options):
 def test_conv2d_position_classes_skip_the_zero_padding(N, H, W, C, Co, stride, lib_options):
     """3x3 / pad 1 convolutions whose tile count fits the stream-K pool run position-major (igemm.h "position classes"): a
     tile's rows share one grid position, its K loop walks only the taps that fall inside the image -- on a 3x3 grid 40 % of
-    the products are multiplications by the zero padding.  Forward and data gradient against torch's conv2d (same bound as
-    the dense schedule), with image counts that are not whole tiles (padded class rows), both strides; the skipped products
+    the products are multiplications by the zero padding; the weight gradient runs tap-major and contracts, per tap, only the
+    grid positions at which that tap is inside the image.  Forward, data and weight gradient against torch's conv2d (same
+    bounds as the dense schedule), with image counts that are not whole tiles (padded class rows), both strides; the skipped products
     are exact zeros, so the dense schedule (option no_cls) must agree to the last bits of the fp32 summation order."""
     import ctypes as Ct
     import torch.nn.functional as F
@@ -1421,9 +1422,12 @@ def test_conv2d_position_classes_skip_the_zero_padding(N, H, W, C, Co, stride, l
     x = T(rng.normal(size=(N, C, H, W)).astype(np.float32)).requires_grad_(True)
     w = T((rng.normal(size=(Co, C, 3, 3)) / np.sqrt(C * 9)).astype(np.float32))
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
+    w.requires_grad_(True)
     y = F.conv2d(x, w, None, stride, 1)
     gy = T(rng.normal(size=tuple(y.shape)).astype(np.float32))
     y.backward(gy)
+    wgrad_ref = w.grad.permute(2, 3, 1, 0).reshape(9 * C, Co)
+    w = w.detach()
     lib = L.lib()
     st = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
     d = L.ConvDesc(N, H, W, C, Co, 3, stride, 1)
@@ -1445,11 +1449,15 @@ def test_conv2d_position_classes_skip_the_zero_padding(N, H, W, C, Co, stride, l
         _report(tag + " dgrad", dx.permute(0, 3, 1, 2), x.grad, 2e-5, 2e-5)
         L.check(lib.avvad_conv2d_dgrad(L.ptr(gyd), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 1, L.ptr(ews), ews.numel() * 4, st), "dgrad +=")
         _report(tag + " dgrad accumulate", dx.permute(0, 3, 1, 2), 2 * x.grad, 4e-5, 4e-5)
-        outs[no_cls] = (yd, dx)
+        dw = torch.full((9 * C, Co), float("nan"), device=DEV)
+        L.check(lib.avvad_conv2d_wgrad(L.ptr(xd), L.ptr(gyd), L.ptr(dw), Ct.byref(d), L.ptr(ews), ews.numel() * 4, st), "wgrad")
+        _report(tag + " wgrad", dw, wgrad_ref, 1e-4 * np.sqrt(N), 1e-4)
+        outs[no_cls] = (yd, dx, dw)
         yd2 = torch.empty_like(yd)
         L.check(lib.avvad_conv2d_fwd(L.ptr(xd), L.ptr(wf), L.ptr(yd2), Ct.byref(d), L.ptr(ews), ews.numel() * 4, st), "fwd")
         assert torch.equal(yd, yd2)                              # run to run: the same bits
     assert _max_rel(outs[0][0], outs[1][0]) < 2e-6 and _max_rel(outs[0][1], outs[1][1]) < 4e-6
+    assert _max_rel(outs[0][2], outs[1][2]) < 1e-5
 
 
 def test_conv2d_refuses_kernels_beyond_the_tap_mask():
