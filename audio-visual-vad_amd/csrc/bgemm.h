@@ -429,7 +429,7 @@ static inline int launch_cls(const AOp& a, const BOp& b, const Epi& e, int Mp, i
   long G = (long)cus * 2;
   if (G * BM * BN > (long)igemm::SLAB_FLOATS) G = (long)(igemm::SLAB_FLOATS / ((size_t)BM * BN));
   const long R = e.sched.total();
-  if (ntiles > G || R <= 0 || (double)R * (double)G >= 4.0e9) return AVVAD_EINVAL;
+  if (R <= 0 || (double)R * (double)G >= 4.0e9) return AVVAD_EINVAL;
   if (G > R / 4) G = R / 4 > 0 ? R / 4 : 1;
   bool stat = false;
   if constexpr (HasStat<Epi>::value) {

@@ -240,7 +240,10 @@ __global__ void __launch_bounds__(256) unpack_all(const UnpackTab tab) {
 // then 32 coalesced 128-byte row stores.
 __global__ void __launch_bounds__(256)
     stem_fwd_mfma(const float* __restrict__ x, const float* __restrict__ wf, float* __restrict__ y, int H, int W, int Ho, int Wo,
-                  int LDW) {
+                  int LDW, double* __restrict__ stat) {
+  // stat (may be null): BatchNorm batch statistics fused -- stat[(n * 2 + 0) * 64 + c] = sum over frame n's pixels of y[.][c],
+  // [(n * 2 + 1) * 64 + c] = sum of squares (one chunk per frame; bn_finalize adds the chunks in order)
+  __shared__ double red[4 * 64 * 2];
   extern __shared__ float img[];                     // (H + 6) x LDW, zero border of 3
   const int n = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -268,6 +271,7 @@ __global__ void __launch_bounds__(256)
   const int npix = Ho * Wo;
   const int ntile = (npix + 31) >> 5;
   float* yn = y + (long)n * npix * 64;
+  float sf0 = 0.f, qf0 = 0.f, sf1 = 0.f, qf1 = 0.f;
   for (int tile = wave; tile < ntile; tile += 4) {
     const int pix = tile * 32 + li;
     const int pc = pix < npix ? pix : 0;              // clamped: rows beyond the frame are computed and dropped
@@ -290,8 +294,27 @@ __global__ void __launch_bounds__(256)
       if (p < npix) {
         yn[(long)p * 64 + li] = acc0[r];
         yn[(long)p * 64 + 32 + li] = acc1[r];
+        sf0 += acc0[r]; qf0 = fmaf(acc0[r], acc0[r], qf0);
+        sf1 += acc1[r]; qf1 = fmaf(acc1[r], acc1[r], qf1);
       }
     }
+  }
+  if (stat == nullptr) return;
+  double d[4] = {(double)sf0, (double)qf0, (double)sf1, (double)qf1};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) d[k] += __shfl_xor(d[k], 32, 64);
+  if (lh == 0) {
+    red[(wave * 64 + li) * 2 + 0] = d[0]; red[(wave * 64 + li) * 2 + 1] = d[1];
+    red[(wave * 64 + 32 + li) * 2 + 0] = d[2]; red[(wave * 64 + 32 + li) * 2 + 1] = d[3];
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x;
+    double a = 0, b = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { a += red[(w * 64 + c) * 2 + 0]; b += red[(w * 64 + c) * 2 + 1]; }
+    stat[((long)n * 2 + 0) * 64 + c] = a;
+    stat[((long)n * 2 + 1) * 64 + c] = b;
   }
 }
 
@@ -332,10 +355,22 @@ __global__ void stem_bn_relu_pool(const float* __restrict__ c0, const float* __r
 
 // stem backward of pool+relu: g0[n,h,w,c] = sum of dp0 over the pooled windows whose recorded arg-max is this element,
 // masked by the ReLU (an all-zero window's arg-max carries no gradient).
-__global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
-                                   const unsigned* __restrict__ am, const float* __restrict__ dp0, float* __restrict__ g0,
-                                   int N, int Hc, int Wc, int Hp, int Wp) {
+// part (may be null; needs gridDim.x * blockDim.x % 16 == 0): the BatchNorm backward's column sums of the stem, fused -- per
+// workgroup sum g0 and sum g0 * xhat per channel (what col_reduce<1> would read c0 and g0 again for), chunk = workgroup
+__global__ void __launch_bounds__(256)
+    stem_pool_relu_bwd(const float* __restrict__ c0, const float* __restrict__ scale, const float* __restrict__ shift,
+                       const unsigned* __restrict__ am, const float* __restrict__ dp0, float* __restrict__ g0,
+                       int N, int Hc, int Wc, int Hp, int Wp, const float* __restrict__ mean = nullptr,
+                       const float* __restrict__ invstd = nullptr, double* __restrict__ part = nullptr) {
+  __shared__ double sm[256 * 8];
   const long total = (long)N * Hc * Wc * 16;
+  float s4[4] = {0.f, 0.f, 0.f, 0.f}, q4[4] = {0.f, 0.f, 0.f, 0.f};
+  float mu[4] = {0.f, 0.f, 0.f, 0.f}, is[4] = {1.f, 1.f, 1.f, 1.f};
+  if (part) {
+    const int qc = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) & 15);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { mu[k] = mean[qc * 4 + k]; is[k] = invstd[qc * 4 + k]; }
+  }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
     const int q = (int)(i & 15);
     long r = i >> 4;
@@ -362,6 +397,23 @@ __global__ void stem_pool_relu_bwd(const float* __restrict__ c0, const float* __
         if (pos[3] && (a >> 24) == me) g[3] += dp.w;
       }
     reinterpret_cast<float4*>(g0)[i] = make_float4(g[0], g[1], g[2], g[3]);
+    if (part) {
+      const float xv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { s4[k] += g[k]; q4[k] = fmaf(g[k], (xv[k] - mu[k]) * is[k], q4[k]); }
+    }
+  }
+  if (part == nullptr) return;
+  // 256 threads = 16 row groups x 16 channel quads (thread t: quad t & 15): fixed-order sums in LDS
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { sm[threadIdx.x * 8 + k] = (double)s4[k]; sm[threadIdx.x * 8 + 4 + k] = (double)q4[k]; }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int c = threadIdx.x, cq = c >> 2, cj = c & 3;
+    double a = 0, b = 0;
+    for (int l = 0; l < 16; ++l) { a += sm[(l * 16 + cq) * 8 + cj]; b += sm[(l * 16 + cq) * 8 + 4 + cj]; }
+    part[((long)blockIdx.x * 2 + 0) * 64 + c] = a;
+    part[((long)blockIdx.x * 2 + 1) * 64 + c] = b;
   }
 }
 
@@ -488,11 +540,23 @@ static inline bool fits_u30(long n) { return n >= 0 && n < (1L << 30); }
 static inline bool taps_fit(const Geom& g) { return g.KS * g.KS <= 32; }
 // operands below 2 GiB take the buffer-addressed gathers (conv_ops.h "BUF")
 static inline bool fits_buf(long n_floats) { return n_floats >= 0 && n_floats < (1L << 29) - 64; }
+// the stem's LDS-resident-frame kernels serve this geometry (7x7 / 2, 1 -> 64 channels, a padded frame within 48 KB of LDS)
+static inline bool stem_kernel_ok(const Geom& g) {
+  const int LDW = (g.W + 6) | 1;
+  return g.C == 1 && g.KS == 7 && g.stride == 2 && g.pad == 3 && g.Co == 64 && (size_t)(g.H + 6) * LDW * sizeof(float) <= 48 * 1024 &&
+         !avvad_tune().no_stem_kernel;
+}
 // rows per M tile of the forward GEMM of convolution g (what the fused BatchNorm statistics are laid out by), 0: the stem
 static inline int fwd_tile_rows(const Geom& g) {
   if (g.C == 1) return 0;
   if (avvad_tune().bf16 == 1) return 128;                   // the bf16 engine's tiles (bgemm.h)
   return g.Co <= 64 && !avvad_tune().no_tall ? 256 : 128;
+}
+// most tiles a position-class product may have (every tile is in the stream-K pool: about one split tile per worker, so the
+// fix-up's traffic grows with the tile count; option "cls_cap" overrides)
+static inline long cls_tile_cap() {
+  if (avvad_tune().cls_cap > 0) return avvad_tune().cls_cap;
+  return 4L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256);     // (measured: 2/CU -> 4/CU: step -0.07 ms)
 }
 // ---- position classes (igemm.h): 3x3 / pad 1 convolutions whose tile count fits the stream-K pool skip the zero padding
 static inline bool cls_common(const Geom& g, float* slab) {
@@ -503,13 +567,13 @@ static inline bool cls_common(const Geom& g, float* slab) {
 static inline bool conv_fwd_cls_ok(const Geom& g, float* slab) {
   if (!cls_common(g, slab) || g.Co % 4 || g.Co < 128) return false;
   const long tiles = (long)g.Ho * g.Wo * cdiv(g.N, 128) * cdiv(g.Co, 128);
-  return tiles <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256) &&
+  return tiles <= cls_tile_cap() &&
          fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf(9L * g.C * g.Co);
 }
 static inline bool conv_dgrad_cls_ok(const Geom& g, float* slab) {
   if (!cls_common(g, slab) || g.stride != 1 || g.C % 4 || g.C < 128) return false;
   const long tiles = (long)g.H * g.W * cdiv(g.N, 128) * cdiv(g.C, 128);
-  return tiles <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256) &&
+  return tiles <= cls_tile_cap() &&
          fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && fits_buf(9L * g.C * g.Co);
 }
 static int conv_fwd_cls(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
@@ -539,12 +603,12 @@ template <bool BUF>
 static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
   const int M = g.N * g.Ho * g.Wo, K = g.KS * g.KS * g.C;
   igemm::EpiStore e{y, g.Co, nullptr, 0};
-  e.stat = g.C == 1 ? nullptr : stat;
+  e.stat = g.C == 1 ? nullptr : stat;       // (the stem's own kernel takes `stat` directly, see below)
   if (g.C == 1) {
     const int LDW = (g.W + 6) | 1;
     const size_t lds = (size_t)(g.H + 6) * LDW * sizeof(float);
     if (g.KS == 7 && g.stride == 2 && g.pad == 3 && g.Co == 64 && lds <= 48 * 1024 && !avvad_tune().no_stem_kernel) {
-      hipLaunchKernelGGL(stem_fwd_mfma, dim3(g.N), dim3(256), lds, s, x, wf, y, g.H, g.W, g.Ho, g.Wo, LDW);
+      hipLaunchKernelGGL(stem_fwd_mfma, dim3(g.N), dim3(256), lds, s, x, wf, y, g.H, g.W, g.Ho, g.Wo, LDW, stat);
       AVVAD_LAUNCH_CHECK();
       return AVVAD_OK;
     }
@@ -657,7 +721,7 @@ static int conv_wgrad_t(const float* x, const float* dy, float* pk, const Geom& 
 // weight gradient by taps (igemm.h TapSched): only the grid positions at which a tap is inside the image are contracted
 static inline bool conv_wgrad_tap_ok(const Geom& g, float* slab) {
   if (!cls_common(g, slab) || g.C % 128 || g.Co % 4 || g.Co < 128) return false;
-  return 9L * (g.C / 128) * cdiv(g.Co, 128) <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256) &&
+  return 9L * (g.C / 128) * cdiv(g.Co, 128) <= cls_tile_cap() &&
          fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.N * g.Ho * g.Wo * g.Co);
 }
 static inline igemm::TapSched tap_sched(const Geom& g, int tiles_per_tap) {
@@ -695,11 +759,11 @@ static inline bool cls16_common(const Geom& g, float* slab) {
 }
 static inline bool conv_fwd16_cls_ok(const Geom& g, float* slab) {
   if (!cls16_common(g, slab) || g.Co < 128) return false;
-  return (long)g.Ho * g.Wo * cdiv(g.N, 128) * cdiv(g.Co, 128) <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256);
+  return (long)g.Ho * g.Wo * cdiv(g.N, 128) * cdiv(g.Co, 128) <= cls_tile_cap();
 }
 static inline bool conv_dgrad16_cls_ok(const Geom& g, float* slab) {
   if (!cls16_common(g, slab) || g.stride != 1 || g.C < 128) return false;
-  return (long)g.H * g.W * cdiv(g.N, 128) * cdiv(g.C, 128) <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256);
+  return (long)g.H * g.W * cdiv(g.N, 128) * cdiv(g.C, 128) <= cls_tile_cap();
 }
 static int conv_fwd16(const float* x16, const float* wf16, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
   if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
@@ -778,7 +842,7 @@ static int conv_wgrad16(const float* x16, const float* dy16, float* pk, const Ge
   const int T = g.KS * g.KS, M = T * g.C, K = g.N * g.Ho * g.Wo;
   if ((unsigned long)(K + bgemm::BKU) * (unsigned long)(g.Ho * g.Wo) >= 0x100000000ull) return AVVAD_EINVAL;   // fast_div range
   if (cls16_common(g, slab) && g.C % 128 == 0 && g.Co >= 128 &&
-      9L * (g.C / 128) * cdiv(g.Co, 128) <= 2L * ((avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256)) {
+      9L * (g.C / 128) * cdiv(g.Co, 128) <= cls_tile_cap()) {
     const igemm::TapSched sc = tap_sched(g, (g.C / 128) * cdiv(g.Co, 128));
     Geom gq = g;
     gq.C = g.C / 2; gq.Co = g.Co / 2;                        // operand elements are bf16 pairs
@@ -815,6 +879,8 @@ static StatCtx stat_ctx(Plan* p, float* ws, long M, int C) {
 // where conv i's forward can leave its fused statistics (null: take the separate column-reduction pass)
 static double* fused_stat(Plan* p, float* ws, int i, const avvad_trunk_desc* d) {
   const int rows = fwd_tile_rows(p->geom[i]);
+  if (i == 0 && d->training && !avvad_tune().no_fused_stats && stem_kernel_ok(p->geom[0]) && (long)p->N * 64 <= (long)STAT_CHUNKS * MAXC)
+    return reinterpret_cast<double*>(ws + p->part);      // one chunk per frame, written by stem_fwd_mfma
   if (!d->training || rows == 0 || avvad_tune().no_fused_stats) return nullptr;
   const long chunks = fwd_stat_chunks(p->geom[i], ws + p->slab);
   if (chunks * p->conv[i].cout > (long)STAT_CHUNKS * MAXC) return nullptr;      // the partial-sum buffer's size
@@ -825,7 +891,7 @@ static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, cons
   const int C = p->conv[i].cout;
   StatCtx sc = stat_ctx(p, ws, M, C);
   if (fused_stat(p, ws, i, d)) {
-    sc.nchunk = fwd_stat_chunks(p->geom[i], ws + p->slab);   // one chunk per M tile of the conv's GEMM
+    sc.nchunk = i == 0 ? p->N : fwd_stat_chunks(p->geom[i], ws + p->slab);   // one chunk per M tile of the conv's GEMM (stem: per frame)
   } else if (d->training) {
     hipLaunchKernelGGL(col_reduce<0>, dim3(sc.nchunk), dim3(256), 0, s, craw, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, M, C, sc.rows_per_chunk, sc.part);
@@ -843,7 +909,8 @@ static int bn_prepare(Plan* p, float* ws, int i, const float* craw, long M, cons
 static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float* dy, const float* ymask, float* dx,
                        float* gout, long M, const avvad_trunk_params* prm, const avvad_trunk_grads* g,
                        const avvad_trunk_desc* d, hipStream_t s, bool own_relu = false, const unsigned char* qmask = nullptr,
-                       bool out16 = false) {
+                       bool out16 = false, int reduced_chunks = 0) {
+  // reduced_chunks > 0: the column sums are already in the partial-sum buffer (that many chunks), written by the producer of dy
   // out16 (the bf16 data path): dx is stored as bf16, and the block output's ReLU mask comes from the byte mask in BOTH
   // passes (the activation itself is bf16 there)
   const int C = p->conv[i].cout;
@@ -856,8 +923,11 @@ static int bn_backward(Plan* p, float* ws, int i, const float* xraw, const float
   // activation (32.5 -> 28.2 us); the column reduction keeps the float activation -- with byte loads it got 9 % SLOWER.
   if (own_relu) ymask = nullptr;
   const bool qred = out16 && qmask != nullptr;
-  hipLaunchKernelGGL(col_reduce<1>, dim3(sc.nchunk), dim3(256), 0, s, xraw, dy, qred ? (const float*)nullptr : ymask, mean, invstd, M, C,
-                     sc.rows_per_chunk, sc.part, msc, msh, qred ? qmask : (const unsigned char*)nullptr);
+  if (reduced_chunks > 0)
+    sc.nchunk = reduced_chunks;
+  else
+    hipLaunchKernelGGL(col_reduce<1>, dim3(sc.nchunk), dim3(256), 0, s, xraw, dy, qred ? (const float*)nullptr : ymask, mean, invstd, M, C,
+                       sc.rows_per_chunk, sc.part, msc, msh, qred ? qmask : (const unsigned char*)nullptr);
   hipLaunchKernelGGL(bn_bwd_finalize, dim3(cdiv(C, FIN_CH)), dim3(256), 0, s, sc.part, sc.nchunk, M, C, prm->bn_w[i], invstd,
                      d->training, g->bn_w[i], g->bn_b[i], ws + p->coef);
   const long nq = M * C / 4;
@@ -1036,7 +1106,7 @@ extern "C" int avvad_trunk_fwd(const float* frames, const avvad_trunk_params* pr
   }
   // stem
   const long N = d->N;
-  if ((rc = conv_fwd(frames, ws + p.wf[0], ws + p.c0, p.geom[0], s, ws + p.slab))) return rc;
+  if ((rc = conv_fwd(frames, ws + p.wf[0], ws + p.c0, p.geom[0], s, ws + p.slab, fused_stat(&p, ws, 0, d)))) return rc;
   const long M0 = N * p.h[1] * p.w[1];
   if ((rc = bn_prepare(&p, ws, 0, ws + p.c0, M0, prm, d, s))) return rc;
   {
@@ -1169,12 +1239,17 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
   // stem: G0 = d p0
   if (g->conv_w[0] || g->bn_w[0] || g->bn_b[0]) {
     float* g0 = ws + p.g0;
-    hipLaunchKernelGGL(stem_pool_relu_bwd, dim3(ew_grid(N * p.h[1] * p.w[1] * 16)), dim3(256), 0, s, ws + p.c0,
+    // the BatchNorm backward's column sums (sum g0, sum g0 xhat) are formed here, where g0 is produced: 2048 workgroups = chunks
+    const bool fuse0 = !avvad_tune().no_fused_stats;
+    int grid0 = ew_grid(N * p.h[1] * p.w[1] * 16);
+    if (fuse0 && grid0 > 2048) grid0 = 2048;
+    hipLaunchKernelGGL(stem_pool_relu_bwd, dim3(grid0), dim3(256), 0, s, ws + p.c0,
                        ws + p.bn_scale, ws + p.bn_shift, reinterpret_cast<const unsigned*>(ws + p.am), G0, g0, d->N, p.h[1], p.w[1],
-                       p.h[2], p.w[2]);
+                       p.h[2], p.w[2], fuse0 ? ws + p.bn_mean : (const float*)nullptr, fuse0 ? ws + p.bn_invstd : (const float*)nullptr,
+                       fuse0 ? reinterpret_cast<double*>(ws + p.part) : (double*)nullptr);
     const long M0 = N * p.h[1] * p.w[1];
     // in place: d c0 overwrites g0
-    if ((rc = bn_backward(&p, ws, 0, ws + p.c0, g0, nullptr, g0, nullptr, M0, prm, g, d, s))) return rc;
+    if ((rc = bn_backward(&p, ws, 0, ws + p.c0, g0, nullptr, g0, nullptr, M0, prm, g, d, s, false, nullptr, false, fuse0 ? grid0 : 0))) return rc;
     if ((rc = wgrad(0, frames, g0))) return rc;
   }
   {
