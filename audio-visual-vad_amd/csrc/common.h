@@ -46,9 +46,20 @@ struct AvvadTune {
   int cls_cap;              // tuning aid: most tiles a position-class product may have (0 = two per CU)
   int no_cls;               // 3x3 convolutions without the position-class schedule (zero padding multiplied like everything else)
   int no_fused_stats;       // BatchNorm batch statistics by the separate column-reduction pass instead of the convolution's epilogue
+  int bwd_max_cus;          // the same cap, applied to the BACKWARD entry points only (that is when the gradient all-reduce runs)
   int max_cus;              // cap on the CUs a persistent grid occupies (0 = all 256): leaves room for RCCL kernels
 };
 AvvadTune& avvad_tune();
+// Backward entry points: while one is on the host's call stack the persistent grids leave CUs to RCCL (option bwd_max_cus).
+// (The options table is process-wide and the host side of a process is single-threaded per device: DESIGN.md 5.)
+struct BwdCuCap {
+  int saved;
+  BwdCuCap() : saved(avvad_tune().max_cus) {
+    const int b = avvad_tune().bwd_max_cus;
+    if (b > 0 && (saved <= 0 || b < saved)) avvad_tune().max_cus = b;
+  }
+  ~BwdCuCap() { avvad_tune().max_cus = saved; }
+};
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

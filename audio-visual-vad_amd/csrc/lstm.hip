@@ -567,6 +567,7 @@ extern "C" int avvad_lstm_layer_bwd(const float* x, const float* w_ih, const flo
                                     float* dx, float* dw_ih, float* dw_hh, float* db_ih, float* db_hh,
                                     const avvad_lstm_desc* d, void* wsv, size_t ws_bytes, avvad_stream_t sv) {
   AVVAD_ENTER();
+  BwdCuCap cu_cap;
   if (!x || !w_ih || !w_hh || !y || !dy || !d || !wsv || !d->lengths) return AVVAD_EINVAL;
   hipStream_t s = (hipStream_t)sv;
   Ws w = carve(d, (float*)wsv);

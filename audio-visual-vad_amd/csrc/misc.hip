@@ -30,11 +30,12 @@ const OptName kOpts[] = {
     {"no_cls", "AVVAD_NO_CLS", &AvvadTune::no_cls},
     {"cls_cap", "AVVAD_CLS_CAP", &AvvadTune::cls_cap},
     {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
+    {"bwd_max_cus", "AVVAD_BWD_MAX_CUS", &AvvadTune::bwd_max_cus},
 };
 int parse_opt(const char* name, const char* v) {
   if (!strcmp(name, "igemm_variant")) return v[0] == 'd' ? 0 : (v[0] == 's' ? 1 : (v[0] == 'w' ? 2 : atoi(v)));
   if (!strcmp(name, "no_streamk")) return v[0] == 'a' ? 1 : (v[0] >= '0' && v[0] <= '9' && !v[1] ? 10 + (v[0] - '0') : atoi(v));
-  if (!strcmp(name, "max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid") || !strcmp(name, "wn_dx") || !strcmp(name, "wn_bwd_t") || !strcmp(name, "no_fixup1") || !strcmp(name, "cls_cap")) return atoi(v);
+  if (!strcmp(name, "max_cus") || !strcmp(name, "bwd_max_cus") || !strcmp(name, "wn_flat") || !strcmp(name, "wn_grid") || !strcmp(name, "wn_dx") || !strcmp(name, "wn_bwd_t") || !strcmp(name, "no_fixup1") || !strcmp(name, "cls_cap")) return atoi(v);
   return (v[0] && strcmp(v, "0")) ? 1 : 0;
 }
 }  // namespace

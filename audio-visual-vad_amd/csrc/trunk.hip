@@ -1180,6 +1180,7 @@ extern "C" int avvad_trunk_bwd(const float* frames, const avvad_trunk_params* pr
                                const avvad_trunk_grads* g, const avvad_trunk_desc* d, void* wsv, size_t ws_bytes,
                                avvad_stream_t sv) {
   AVVAD_ENTER();
+  BwdCuCap cu_cap;
   if (!frames || !prm || !dfeat || !g || !d || !wsv || !d->save_for_backward) return AVVAD_EINVAL;
   hipStream_t s = (hipStream_t)sv;
   Plan p;

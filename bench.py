@@ -371,7 +371,8 @@ def main():
     dev = torch.device("cuda", local)
     reserve = args.reserve_cus if args.reserve_cus >= 0 else (RESERVE_CUS_DP if world > 1 else 0)
     if reserve:
-        L.set_option("max_cus", 256 - reserve)
+        # only the BACKWARD entry points leave CUs free: that is when the bucketed all-reduce runs (the forward has no exchange)
+        L.set_option("bwd_max_cus", 256 - reserve)
     if args.dtype == "bf16":
         if L.lib().avvad_set_option(b"bf16", 1) != 0:
             raise SystemExit("this build of libavvad_hip.so has no bf16 path")

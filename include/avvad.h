@@ -57,7 +57,10 @@ int avvad_abi_version(void);
  *   2: round 2's form, fp32 storage everywhere and operands rounded while staging.  BatchNorm statistics, LSTM cell, loss,
  *   Adam and every accumulation stay fp32 in both),
  *   "max_cus" (cap on the CUs a persistent grid occupies, so that RCCL's kernels find free CUs during data-parallel
- *   training).
+ *   training), "bwd_max_cus" (the same cap applied only while a backward entry point runs: the gradient all-reduce overlaps
+ *   the backward pass, the forward keeps the whole chip), "no_cls" (1 = 3x3 convolutions multiply their zero padding like
+ *   everything else instead of running position-major), "cls_cap", "no_fused_stats" (1 = BatchNorm statistics by separate
+ *   column-reduction passes instead of the producing kernels' epilogues).
  * Initial values come from AVVAD_<NAME> in the environment, read once.  Returns AVVAD_EINVAL for an unknown name. */
 int avvad_set_option(const char* name, int value);
 int avvad_get_option(const char* name);

@@ -166,6 +166,35 @@ def test_engine_cu_cap_option(lib_options):
     _report("engine with 232 of 256 CUs", c1, c0, 2e-4, 1e-5)
 
 
+def test_backward_only_cu_reservation(lib_options):
+    """option bwd_max_cus (bench.py at N > 1): only the BACKWARD entry points leave CUs to RCCL -- the gradient all-reduce
+    overlaps the backward pass, the forward keeps the whole chip.  The cap is in force exactly while a backward entry point
+    runs (the forward is bit-identical to the uncapped one, the gradients differ by the summation order of a different worker
+    count), and the process-wide max_cus is back to its value afterwards."""
+    from avvad import _lib as L, nn as avnn
+    from packages.models.Video_Net import DeepVAD_video
+    torch.manual_seed(1)
+    m = DeepVAD_video(1, 8, 1).to(DEV).train()
+    x = torch.randn(160, 67, 67, device=DEV)
+    Gd = torch.randn(160, 512, device=DEV) * 1e-3
+
+    def run():
+        for p in m.features.parameters():
+            p.grad = None
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        f = avnn.trunk_forward(m.features, x, True)
+        (f * Gd).sum().backward()
+        m.load_state_dict(sd)                     # (running statistics back: both runs start from the same state)
+        return f.detach().clone(), [p.grad.clone() for p in m.features.parameters()]
+    f0, g0 = run()
+    lib_options("bwd_max_cus", 224)
+    f1, g1 = run()
+    assert L.get_option("max_cus") == 0 and torch.equal(f0, f1)
+    worst = max(float((a - b).norm() / b.norm().clamp_min(1e-30)) for a, b in zip(g1, g0))
+    print("backward with 224 of 256 CUs: worst relL2 of a gradient tensor %.2e" % worst)
+    assert 0 < worst < 1e-4
+
+
 # ------------------------------------------------------------------------------------------ WaveNet encoder
 @pytest.mark.parametrize("name,alt", [("wn_tiny", 0), ("wn_fw3_qc2", 0), ("wn_nobias", 0), ("wn_w0", 0), ("wn_w0_t16", 0),
                                       ("wn_nobias", 1), ("wn_w0", 1), ("wn_w0_t16", 1), ("wn_w0", 2), ("wn_w0_t16", 2),
