@@ -84,11 +84,15 @@ struct RowPairsCls {
   static constexpr int VEC = 4;
   typedef igemm::NoCtx Ctx;
   const float* p;
-  int ld, X, T, KS, NP, flip;
-  unsigned mg_NP;
+  int ld, X, T, KS, flip;
+  igemm::ClassRow cr;
   igemm::ClassSched sc;
   __device__ __forceinline__ Ctx prep(int) const { return Ctx(); }
-  __device__ __forceinline__ ClassTile tile(int m0) const { return igemm::class_tile(sc, igemm::dev_div(m0, mg_NP), flip != 0); }
+  __device__ __forceinline__ ClassTile tile(int m0) const {
+    int n, pp;
+    cr.split(m0, n, pp);
+    return igemm::class_tile(sc, pp, flip != 0);
+  }
   __device__ __forceinline__ void load(const Ctx&, const ClassTile& t, int x, int k0, int kin, float* v) const {
     int cc, kh, kw;
     convop::cls_tap(t, k0, cc, kh, kw);

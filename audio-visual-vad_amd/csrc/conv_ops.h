@@ -308,8 +308,8 @@ struct WgradX {
   }
 };
 
-// ---- position-class operands (igemm.h "position classes"): GEMM rows are ordered grid-position-major, m' = p * NP + n, so
-// that a tile's rows share their set of live taps and the K loop walks only those -- no validity masks at all.  3x3 / pad 1.
+// ---- position-class operands (igemm.h "position classes"): a tile's 128 rows are 128 images at ONE grid position (ClassRow), so
+// that they share their set of live taps and the K loop walks only those -- no validity masks at all.  3x3 / pad 1.
 // K tile q of a tile of class (a x b live taps from (kh_lo, kw_lo)):  q = cc * (a b) + (kh - kh_lo) * b + (kw - kw_lo).
 __device__ __forceinline__ void cls_tap(const igemm::ClassTile& t, int k0, int& cc, int& kh, int& kw) {
   const int q = k0 >> 5, ab = t.a * t.b;
@@ -325,18 +325,23 @@ struct Im2colFwdCls {
   struct Ctx { unsigned boff; int ok; };
   const float* x;
   Geom g;
-  int NP, rows;
-  unsigned mg_NP;
+  int rows;
+  igemm::ClassRow cr;
   igemm::ClassSched sc;
   __device__ __forceinline__ Ctx prep(int m) const { return prep2(m, 0); }
   __device__ __forceinline__ Ctx prep2(int m, int kin) const {
-    const int n = m - igemm::dev_div(m, mg_NP) * NP;
+    int n, p;
+    cr.split(m, n, p);
     Ctx c;
     c.ok = n < rows;
     c.boff = ((unsigned)n * (unsigned)(g.H * g.W) * (unsigned)g.C + (unsigned)kin) * 4u;
     return c;
   }
-  __device__ __forceinline__ igemm::ClassTile tile(int m0) const { return igemm::class_tile(sc, igemm::dev_div(m0, mg_NP), false); }
+  __device__ __forceinline__ igemm::ClassTile tile(int m0) const {
+    int n, p;
+    cr.split(m0, n, p);
+    return igemm::class_tile(sc, p, false);
+  }
   __device__ __forceinline__ void load(const Ctx& c, const igemm::ClassTile& t, int, int k0, int, float* v) const {
     int cc, kh, kw;
     cls_tap(t, k0, cc, kh, kw);
@@ -352,18 +357,23 @@ struct Im2colDgradCls {
   struct Ctx { unsigned boff; int ok; };
   const float* dy;
   Geom g;
-  int NP, rows;
-  unsigned mg_NP;
+  int rows;
+  igemm::ClassRow cr;
   igemm::ClassSched sc;
   __device__ __forceinline__ Ctx prep(int m) const { return prep2(m, 0); }
   __device__ __forceinline__ Ctx prep2(int m, int kin) const {
-    const int n = m - igemm::dev_div(m, mg_NP) * NP;
+    int n, p;
+    cr.split(m, n, p);
     Ctx c;
     c.ok = n < rows;
     c.boff = ((unsigned)n * (unsigned)(g.Ho * g.Wo) * (unsigned)g.Co + (unsigned)kin) * 4u;
     return c;
   }
-  __device__ __forceinline__ igemm::ClassTile tile(int m0) const { return igemm::class_tile(sc, igemm::dev_div(m0, mg_NP), true); }
+  __device__ __forceinline__ igemm::ClassTile tile(int m0) const {
+    int n, p;
+    cr.split(m0, n, p);
+    return igemm::class_tile(sc, p, true);
+  }
   __device__ __forceinline__ void load(const Ctx& c, const igemm::ClassTile& t, int, int k0, int, float* v) const {
     int cc, kh, kw;
     cls_tap(t, k0, cc, kh, kw);
@@ -380,8 +390,8 @@ struct ColTapRowsCls {
   struct Ctx { unsigned boff; int ok; };
   const float* p;
   long ld;
-  int X, C, KS, NP, flip;
-  unsigned mg_NP;
+  int X, C, KS, flip;
+  igemm::ClassRow cr;
   igemm::ClassSched sc;
   __device__ __forceinline__ Ctx prep(int x) const { return prep2(x, 0); }
   __device__ __forceinline__ Ctx prep2(int x, int kl) const {
@@ -390,7 +400,11 @@ struct ColTapRowsCls {
     c.boff = c.ok ? (unsigned)((kl * (int)ld + x) * 4) : 0u;
     return c;
   }
-  __device__ __forceinline__ igemm::ClassTile tile(int m0) const { return igemm::class_tile(sc, igemm::dev_div(m0, mg_NP), flip != 0); }
+  __device__ __forceinline__ igemm::ClassTile tile(int m0) const {
+    int n, pp;
+    cr.split(m0, n, pp);
+    return igemm::class_tile(sc, pp, flip != 0);
+  }
   __device__ __forceinline__ void load(const Ctx& c, const igemm::ClassTile& t, int, int k0, int, float* v) const {
     int cc, kh, kw;
     cls_tap(t, k0, cc, kh, kw);

@@ -65,35 +65,52 @@ struct HasStat<Epi, std::void_t<decltype(Epi::stat)>> : std::true_type {};
 // tile <-> iteration maps in closed form (the live-tap counts are separable: a(ho) = KS - [ho == 0] fs - [ho == Ho-1] ls).
 // Used where the tile count does not exceed the worker count (no data-parallel rounds: every tile is in the pool).
 struct ClassSched {
-  int Ho, Wo, tpc, nchunk;        // grid of position classes; tiles per class (M tiles x N tiles); channel chunks per tap
+  // Tile order: (image block mt, grid position p, N tile nt), nt fastest -- the 128 images of a block are walked through ALL
+  // their positions by neighbouring workers (one XCD after the remap), so the taps' overlapping pixel reads stay in that XCD's
+  // L2 (position-outermost order re-fetched every image once per position from beyond L2: 427 MB per launch, PMC).
+  int Ho, Wo, ntn, nchunk, MB;    // grid of position classes; N tiles; channel chunks per tap; image blocks (of 128)
   int KS, fsh, lsh, fsw, lsw;     // first / last row (column) of the grid loses fsh / lsh (fsw / lsw) taps
   __host__ __device__ int ah(int h) const { return KS - (h == 0 ? fsh : 0) - (h == Ho - 1 ? lsh : 0); }
   __host__ __device__ int bw(int w) const { return KS - (w == 0 ? fsw : 0) - (w == Wo - 1 ? lsw : 0); }
   __host__ __device__ int Ah(int h) const { return KS * h - (h > 0 ? fsh : 0) - (h > Ho - 1 ? lsh : 0); }   // sum of ah below h
   __host__ __device__ int Bw(int w) const { return KS * w - (w > 0 ? fsw : 0) - (w > Wo - 1 ? lsw : 0); }
-  __host__ __device__ long total() const { return (long)nchunk * tpc * Ah(Ho) * Bw(Wo); }
+  __host__ __device__ long per_block() const { return (long)nchunk * ntn * Ah(Ho) * Bw(Wo); }
+  __host__ __device__ long total() const { return per_block() * MB; }
   __host__ __device__ int len(int tile) const {
-    const int p = tile / tpc, ho = p / Wo, wo = p - ho * Wo;
+    const int p = (tile / ntn) % (Ho * Wo), ho = p / Wo, wo = p - ho * Wo;
     return ah(ho) * bw(wo) * nchunk;
   }
   __host__ __device__ long base(int tile) const {      // K tiles of all tiles in front of `tile`
-    const int p = tile / tpc, r = tile - p * tpc, ho = p / Wo, wo = p - ho * Wo;
-    return (long)nchunk * ((long)tpc * (Ah(ho) * Bw(Wo) + ah(ho) * Bw(wo)) + (long)r * ah(ho) * bw(wo));
+    const int q = tile / ntn, nt = tile - q * ntn, P = Ho * Wo, mt = q / P, p = q - mt * P, ho = p / Wo, wo = p - ho * Wo;
+    return per_block() * mt + (long)nchunk * ((long)ntn * (Ah(ho) * Bw(Wo) + ah(ho) * Bw(wo)) + (long)nt * ah(ho) * bw(wo));
   }
   __device__ void locate(long it, int& tile, int& kt, int& klen) const {
-    const long c = (long)nchunk * tpc;
+    const long pb = per_block();
+    const int mt = (int)(it / pb);
+    long rem = it - pb * mt;
+    const long c = (long)nchunk * ntn;
     const int Bt = Bw(Wo);
     int ho = 0;
-    while (ho + 1 < Ho && c * Ah(ho + 1) * Bt <= it) ++ho;
-    long rem = it - c * Ah(ho) * Bt;
+    while (ho + 1 < Ho && c * Ah(ho + 1) * Bt <= rem) ++ho;
+    rem -= c * Ah(ho) * Bt;
     const int a = ah(ho);
     int wo = 0;
     while (wo + 1 < Wo && c * a * Bw(wo + 1) <= rem) ++wo;
     rem -= c * a * Bw(wo);
     klen = a * bw(wo) * nchunk;
-    const int r = (int)(rem / klen);
-    kt = (int)(rem - (long)r * klen);
-    tile = (ho * Wo + wo) * tpc + r;
+    const int nt = (int)(rem / klen);
+    kt = (int)(rem - (long)nt * klen);
+    tile = ((mt * Ho + ho) * Wo + wo) * ntn + nt;
+  }
+};
+// GEMM row m' of a position-class product -> (image n, grid position p):  m' = (mt * P + p) * 128 + r,  n = mt * 128 + r
+struct ClassRow {
+  int P;
+  unsigned mg_P;
+  __device__ __forceinline__ void split(int m, int& n, int& p) const {
+    const int q = m >> 7, mt = mg_P ? (int)__umulhi((unsigned)q, mg_P) : q;
+    p = q - mt * P;
+    n = mt * 128 + (m & 127);
   }
 };
 // what a tile's K loop needs to know about its class: live tap ranges and counts (wave-uniform: kept in scalar registers)
@@ -129,18 +146,24 @@ struct EpiCls {
   int cs = 1;
   double* stat = nullptr;
   int W = 0;           // channels of the output (elements per pixel)
-  int NP = 0, rows = 0;  // padded / real images per class
-  unsigned mg_NP = 0;
+  int rows = 0;        // images
+  ClassRow cr{0, 0u};
   ClassSched sched;
   struct View { float* C; int row0, M; };
-  __device__ __forceinline__ View view(int m0) const {
-    const int p = dev_div(m0, mg_NP);
-    return View{C + (long)p * W, m0 - p * NP, rows};
+  __device__ __forceinline__ View view(int m0) const {      // m0: a tile origin (multiple of 128)
+    int n, p;
+    cr.split(m0, n, p);
+    return View{C + (long)p * W, n, rows};
   }
-  __device__ __forceinline__ bool live(int m) const { return m - dev_div(m, mg_NP) * NP < rows; }
-  __device__ __forceinline__ float* ptr(int m, int n) const {
-    const int p = dev_div(m, mg_NP);
-    return C + (long)p * W + (long)(m - p * NP) * ldc + n;
+  __device__ __forceinline__ bool live(int m) const {
+    int n, p;
+    cr.split(m, n, p);
+    return n < rows;
+  }
+  __device__ __forceinline__ float* ptr(int m, int nn) const {
+    int n, p;
+    cr.split(m, n, p);
+    return C + (long)p * W + (long)n * ldc + nn;
   }
 };
 // The WEIGHT gradient's twin: C[(tap, c)][co] = sum over output pixels.  Rows are tap-major (a 128-row tile = one tap x 128

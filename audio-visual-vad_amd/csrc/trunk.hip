@@ -577,23 +577,25 @@ static inline bool conv_dgrad_cls_ok(const Geom& g, float* slab) {
          fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && fits_buf(9L * g.C * g.Co);
 }
 static int conv_fwd_cls(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
-  const int NP = cdiv(g.N, 128) * 128, P = g.Ho * g.Wo;
+  const int MB = cdiv(g.N, 128), P = g.Ho * g.Wo;
   const int lsh = ((g.Ho - 1) * g.stride - g.pad + 2 > g.H - 1) ? 1 : 0, lsw = ((g.Wo - 1) * g.stride - g.pad + 2 > g.W - 1) ? 1 : 0;
-  const igemm::ClassSched sc{g.Ho, g.Wo, (NP / 128) * cdiv(g.Co, 128), g.C / 32, 3, 1, lsh, 1, lsw};
-  convop::Im2colFwdCls a{x, g, NP, g.N, convop::div_magic(NP), sc};
-  convop::ColTapRowsCls b{wf, g.Co, g.Co, g.C, 3, NP, 0, convop::div_magic(NP), sc};
+  const igemm::ClassSched sc{g.Ho, g.Wo, cdiv(g.Co, 128), g.C / 32, MB, 3, 1, lsh, 1, lsw};
+  const igemm::ClassRow cr{P, convop::div_magic(P)};
+  convop::Im2colFwdCls a{x, g, g.N, cr, sc};
+  convop::ColTapRowsCls b{wf, g.Co, g.Co, g.C, 3, 0, cr, sc};
   igemm::EpiCls e{y, (long)P * g.Co, nullptr, 0};
-  e.stat = stat; e.W = g.Co; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
-  return igemm::launch_cls(a, b, e, P * NP, g.Co, s, slab);
+  e.stat = stat; e.W = g.Co; e.rows = g.N; e.cr = cr; e.sched = sc;
+  return igemm::launch_cls(a, b, e, MB * P * 128, g.Co, s, slab);
 }
 static int conv_dgrad_cls(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
-  const int NP = cdiv(g.N, 128) * 128, P = g.H * g.W;
-  const igemm::ClassSched sc{g.H, g.W, (NP / 128) * cdiv(g.C, 128), g.Co / 32, 3, 1, 1, 1, 1};
-  convop::Im2colDgradCls a{dy, g, NP, g.N, convop::div_magic(NP), sc};
-  convop::ColTapRowsCls b{wd, g.C, g.C, g.Co, 3, NP, 1, convop::div_magic(NP), sc};
+  const int MB = cdiv(g.N, 128), P = g.H * g.W;
+  const igemm::ClassSched sc{g.H, g.W, cdiv(g.C, 128), g.Co / 32, MB, 3, 1, 1, 1, 1};
+  const igemm::ClassRow cr{P, convop::div_magic(P)};
+  convop::Im2colDgradCls a{dy, g, g.N, cr, sc};
+  convop::ColTapRowsCls b{wd, g.C, g.C, g.Co, 3, 1, cr, sc};
   igemm::EpiCls e{dx, (long)P * g.C, nullptr, accumulate ? 1 : 0};
-  e.W = g.C; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
-  return igemm::launch_cls(a, b, e, P * NP, g.C, s, slab);
+  e.W = g.C; e.rows = g.N; e.cr = cr; e.sched = sc;
+  return igemm::launch_cls(a, b, e, MB * P * 128, g.C, s, slab);
 }
 // number of partial-sum chunks the forward of convolution g leaves in its `stat` buffer (one per M tile of its GEMM)
 static inline int fwd_stat_chunks(const Geom& g, float* slab);
@@ -768,16 +770,17 @@ static inline bool conv_dgrad16_cls_ok(const Geom& g, float* slab) {
 static int conv_fwd16(const float* x16, const float* wf16, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
   if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
   if (conv_fwd16_cls_ok(g, slab)) {
-    const int NP = cdiv(g.N, 128) * 128, P = g.Ho * g.Wo;
+    const int MB = cdiv(g.N, 128), P = g.Ho * g.Wo;
     const int lsh = ((g.Ho - 1) * g.stride - g.pad + 2 > g.H - 1) ? 1 : 0, lsw = ((g.Wo - 1) * g.stride - g.pad + 2 > g.W - 1) ? 1 : 0;
-    const igemm::ClassSched sc{g.Ho, g.Wo, (NP / 128) * cdiv(g.Co, 128), g.C / 64, 3, 1, lsh, 1, lsw};
+    const igemm::ClassSched sc{g.Ho, g.Wo, cdiv(g.Co, 128), g.C / 64, MB, 3, 1, lsh, 1, lsw};
+    const igemm::ClassRow cr{P, convop::div_magic(P)};
     Geom gp = g;
     gp.C = g.C / 2;
-    convop::Im2colFwdCls a{x16, gp, NP, g.N, convop::div_magic(NP), sc};
-    bgemm::RowPairsCls b{wf16, 9 * g.C / 2, g.Co, 9, 3, NP, 0, convop::div_magic(NP), sc};
+    convop::Im2colFwdCls a{x16, gp, g.N, cr, sc};
+    bgemm::RowPairsCls b{wf16, 9 * g.C / 2, g.Co, 9, 3, 0, cr, sc};
     igemm::EpiCls e{y, (long)P * g.Co, nullptr, 0};
-    e.stat = stat; e.W = g.Co; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
-    return bgemm::launch_cls<false>(a, b, e, P * NP, g.Co, s, slab);
+    e.stat = stat; e.W = g.Co; e.rows = g.N; e.cr = cr; e.sched = sc;
+    return bgemm::launch_cls<false>(a, b, e, MB * P * 128, g.Co, s, slab);
   }
   const int M = g.N * g.Ho * g.Wo, T = g.KS * g.KS, Kp = T * g.C / 2;
   Geom gp = g;
@@ -823,13 +826,14 @@ static int conv_dgrad16(const float* dy16, const float* wd16, float* dx, const G
     return AVVAD_OK;
   }
   if (conv_dgrad16_cls_ok(g, slab)) {
-    const int NP = cdiv(g.N, 128) * 128, P = g.H * g.W;
-    const igemm::ClassSched sc{g.H, g.W, (NP / 128) * cdiv(g.C, 128), g.Co / 64, 3, 1, 1, 1, 1};
-    convop::Im2colDgradCls a{dy16, gp, NP, g.N, convop::div_magic(NP), sc};
-    bgemm::RowPairsCls b{wd16, Kp, g.C, 9, 3, NP, 1, convop::div_magic(NP), sc};
+    const int MB = cdiv(g.N, 128), P = g.H * g.W;
+    const igemm::ClassSched sc{g.H, g.W, cdiv(g.C, 128), g.Co / 64, MB, 3, 1, 1, 1, 1};
+    const igemm::ClassRow cr{P, convop::div_magic(P)};
+    convop::Im2colDgradCls a{dy16, gp, g.N, cr, sc};
+    bgemm::RowPairsCls b{wd16, Kp, g.C, 9, 3, 1, cr, sc};
     igemm::EpiCls e{dx, (long)P * g.C, nullptr, accumulate ? 1 : 0};
-    e.W = g.C; e.NP = NP; e.rows = g.N; e.mg_NP = convop::div_magic(NP); e.sched = sc;
-    return bgemm::launch_cls<false>(a, b, e, P * NP, g.C, s, slab);
+    e.W = g.C; e.rows = g.N; e.cr = cr; e.sched = sc;
+    return bgemm::launch_cls<false>(a, b, e, MB * P * 128, g.C, s, slab);
   }
   convop::Im2colDgrad<true> a{dy16, gp, M, convop::tap_div(T, g.KS)};
   bgemm::RowPairs b{wd16, Kp, g.C, Kp};

@@ -46,11 +46,11 @@ PEAK_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 MFMA == fp32 vector peak
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 PEAK_HBM_GBS = 8000.0     # HBM3E spec (6.29 TB/s measured copy)
 RESERVE_CUS_DP = 16       # N > 1: CUs the persistent conv grids leave to RCCL's channel workgroups
-# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_summary.py -> profiles/r02_pmc_*_per_kernel.csv);
+# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/pmc_summary.py -> profiles/r03_pmc_*_per_kernel.csv);
 # FETCH_SIZE counts 128-B requests at 64 B on gfx950 -> doubled.  Bytes per launch of the two roofline kernels.
 TRAFFIC = {"conv_fwd": None, "wn_layer": None}
 try:
-    with open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")) as _f:
+    with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")) as _f:
         TRAFFIC.update(json.load(_f))
 except OSError:
     pass
@@ -200,7 +200,7 @@ def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
             "launches_per_step": n_launch, "avg_launch_us": round(1e3 * tot_ms / n_launch, 2),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": TRAFFIC.get("conv_fwd") if dtype == "f32" else None,
-            "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC, profiles/r02_pmc_*_per_kernel.csv)",
+            "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC, profiles/r03_pmc_*_per_kernel.csv)",
             "per_shape": [{"C": a, "Co": b, "HW": c_, "k": d_, "s": e, "us": round(1e3 * f, 1), "TFLOPs": round(g, 1)}
                           for (a, b, c_, d_, e, f, g) in per]}
 
