@@ -167,7 +167,7 @@ def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
     from avvad import _lib as L
     lib = L.lib()
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    tot_flop, tot_ms, n_launch = 0.0, 0.0, 0
+    tot_flop, exe_flop, tot_ms, n_launch = 0.0, 0.0, 0.0, 0
     per = []
     ews = torch.empty(lib.avvad_engine_workspace() // 4, device="cuda")     # the engine's stream-K scratch (caller-allocated)
     for (c, co, h, w, ks, stride, pad) in trunk_conv_shapes(n_frames):
@@ -188,17 +188,27 @@ def roofline_probe(torch, n_frames, reps=5, dtype="f32"):
         flop = 2.0 * n_frames * ho * ho * co * ks * ks * c
         per.append((c, co, h, ks, stride, ms, flop / ms / 1e9))
         tot_flop += flop
+        # products actually executed: 3x3 / pad 1 convolutions that run position-major skip the taps that fall into the
+        # padding (csrc/igemm.h "position classes"; same eligibility rule as csrc/trunk.hip conv_fwd_cls_ok)
+        live = 1.0
+        if ks == 3 and pad == 1 and n_frames >= 128 and ho >= 2 and ho * ho * -(-n_frames // 128) * -(-co // 128) <= 1024:
+            last = 1 if (ho - 1) * stride - pad + 2 > h - 1 else 0
+            live = ((3 * ho - 1 - last) / (3.0 * ho)) ** 2
+        exe_flop += flop * live
         tot_ms += ms
         n_launch += 1
     ach = tot_flop / tot_ms / 1e9
     peak = PEAK_BF16_TFLOPS if dtype == "bf16" else PEAK_F32_TFLOPS
-    kname = ("bgemm::kernel<128,128,false,Im2colFwd<true>,RowPairs,EpiStore> (trunk conv forward on the bf16 data path, Cout>=128: bf16 operands "
-             "in HBM, v_mfma_f32_32x32x16_bf16) + its stream-K fix-up" if dtype == "bf16" else
-             "igemm::kernel<128,128,true,512,Im2colFwd<true>,ColTapRows<true>,EpiStore> (trunk conv forward, Cout>=128, buffer-addressed gathers) + its "
-             "stream-K fix-up")
+    kname = ("bgemm::kernel<128,128,false,Im2colFwd[Cls],RowPairs[Cls],Epi{Store,Cls}> (trunk conv forward on the bf16 data path, Cout>=128: "
+             "bf16 operands in HBM, v_mfma_f32_32x32x16_bf16; position classes on the small grids) + its stream-K fix-up" if dtype == "bf16" else
+             "igemm::kernel<128,128,true,512,Im2colFwd[Cls],ColTapRows[Cls],Epi{Store,Cls}> (trunk conv forward, Cout>=128: fp32 MFMA implicit "
+             "GEMM, buffer-addressed gathers; the 3x3 convolutions of the 9x9 / 5x5 / 3x3 grids run position-major and skip their zero "
+             "padding) + its stream-K fix-up")
     return {"bound": "mfma", "kernel": kname,
             "launches_per_step": n_launch, "avg_launch_us": round(1e3 * tot_ms / n_launch, 2),
             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            # `achieved` counts ALGORITHMIC FLOPs (SURVEY 8d's dense 2*N*Ho*Wo*Co*KS^2*C); the products really multiplied:
+            "executed_tflops": round(exe_flop / tot_ms / 1e9, 2), "executed_frac": round(exe_flop / tot_ms / 1e9 / peak, 4),
             "traffic": TRAFFIC.get("conv_fwd") if dtype == "f32" else None,
             "traffic_unit": "bytes/launch (HBM side, rocprofv3 PMC, profiles/r03_pmc_*_per_kernel.csv)",
             "per_shape": [{"C": a, "Co": b, "HW": c_, "k": d_, "s": e, "us": round(1e3 * f, 1), "TFLOPs": round(g, 1)}
