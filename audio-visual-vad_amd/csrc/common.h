@@ -43,6 +43,7 @@ struct AvvadTune {
   int wn_grid;               // tuning aid: workgroup cap of the wide residual-block kernels (0 = default)
   int wn_bwd_t;             // fused block backward: 0 by the descriptor's shared_device hint, 1 transposed products, 2 high occupancy, 3 resident weights
   int bf16;                 // bf16-input MFMA (fp32 accumulate) for the convolutions and dense GEMMs: BASELINE config 5's arithmetic
+  int stagger;              // the engine's 8-wave kernels WITH the half-tile stagger of waves 4-7 (measured: step +0.14 ms; off)
   int cls_cap;              // tuning aid: most tiles a position-class product may have (0 = two per CU)
   int no_cls;               // 3x3 convolutions without the position-class schedule (zero padding multiplied like everything else)
   int no_fused_stats;       // BatchNorm batch statistics by the separate column-reduction pass instead of the convolution's epilogue

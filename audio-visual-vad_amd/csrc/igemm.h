@@ -516,8 +516,9 @@ template <int BM, int BN, bool DB, int NTH, class AOp, class BOp, class Epi, boo
 //  the residency -- the instrumented -DAVVAD_PROF build did exactly that.  The 4-wave instantiations are left looser:
 //  pinning them to their per_cu made the 64x64 kernels spill.)
 __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 128) ? 2 : 3))
-    kernel(const AOp A, const BOp B, const Epi E, const int M, const int N, const int K, const int ktiles,
+    kernel(const AOp A, const BOp B, const Epi E, const int M, const int N, const int flags, const int ktiles,
            const int full_rounds, const int rem_tiles, const int kchunks, float* __restrict__ const slab) {
+  const bool stagger = (flags & 1) != 0;     // (flags: bit 0 = stagger the two wave halves, see the K loop)
   typedef Stage<AOp, BM, NTH> SA;
   typedef Stage<BOp, BN, NTH> SB;
   // wave grid WGM x WGN: 2 x 2 (256 threads), 2 x 4 (512 threads, 128x128) or 4 x 2 (512 threads, 256x64: the tall tile
@@ -718,13 +719,20 @@ __global__ void __launch_bounds__(NTH, NTH == 512 ? 4 : ((DB || BM * BN < 128 * 
       const float* ap = As + lh * SA::LD + wm * (BM / WGM) + li;
       const float* bp = Bs + lh * SB::LD + wn * (BN / WGN) + li;
       float a[2][TM], b[2][TN];
+      // STAGGER (MI355X_MICROARCH "Two waves per SIMD" item 9): the 8 waves of a workgroup run the same program with one
+      // barrier per K tile, i.e. in lockstep -- both waves of a SIMD reach their staging burst (LDS writes, the next loads'
+      // issue) and their MFMA runs together.  Waves 4-7 therefore stage at the START of the K tile, waves 0-3 in its middle
+      // (any point of the tile is legal: the other LDS buffer's readers finished before the last barrier).  MEASURED on
+      // this kernel (bench.py --ab, same process): the step gets 0.14 ms SLOWER -- two workgroups share a CU here and are
+      // out of phase with each other already -- so the stagger is off unless option "stagger" asks for it.
+      const int stage_ks = (NTH == 512 && stagger && __builtin_amdgcn_readfirstlane(wave) >= 4) ? 0 : BK / 4;
 #pragma unroll
       for (int i = 0; i < TM; ++i) a[0][i] = ap[i * 32];
 #pragma unroll
       for (int j = 0; j < TN; ++j) b[0][j] = bp[j * 32];
 #pragma unroll
       for (int ks = 0; ks < BK / 2; ++ks) {
-        if (DB && ks == BK / 4 && kt + 1 < kt1) {
+        if (DB && ks == stage_ks && kt + 1 < kt1) {
           // MID-tile staging (double-buffered LDS): the wait for tile kt+1's global loads, its LDS writes (other
           // buffer: its readers passed the last barrier) and the issue of tile kt+2's loads sit between the two
           // halves of this tile's MFMAs instead of right behind the barrier, where every wave of both co-resident
@@ -1205,13 +1213,14 @@ static inline int launch(const AOp& a, const BOp& b, const Epi& e_in, int M, int
   } else if (finished) {
     *finished = false;
   }
+  const int kflags = tn.stagger ? 1 : 0;
 #define AVVAD_IGEMM_LAUNCH(DBV, NTHV)                                                                                       \
   do {                                                                                                                      \
     if (bf)                                                                                                                 \
-      hipLaunchKernelGGL((kernel<BM, BN, DBV, NTHV, AOp, BOp, Epi, true>), dim3((int)G), dim3(NTHV), 0, s, a, b, e, M, N, K, \
+      hipLaunchKernelGGL((kernel<BM, BN, DBV, NTHV, AOp, BOp, Epi, true>), dim3((int)G), dim3(NTHV), 0, s, a, b, e, M, N, kflags, \
                          ktiles, fr, rt, kchunks, slab);                                                                    \
     else                                                                                                                    \
-      hipLaunchKernelGGL((kernel<BM, BN, DBV, NTHV, AOp, BOp, Epi, false>), dim3((int)G), dim3(NTHV), 0, s, a, b, e, M, N, K, \
+      hipLaunchKernelGGL((kernel<BM, BN, DBV, NTHV, AOp, BOp, Epi, false>), dim3((int)G), dim3(NTHV), 0, s, a, b, e, M, N, kflags, \
                          ktiles, fr, rt, kchunks, slab);                                                                    \
   } while (0)
   if constexpr (TALL) {
@@ -1256,8 +1265,8 @@ static inline int launch_cls(const AOp& a, const BOp& b, const Epi& e, int Mp, i
     stat = e.stat != nullptr;
     if (stat && (e.cs != 1 || (e.ldc & 3) || (N & 3) || (((uintptr_t)e.C) & 15) || (e.W & 3))) return AVVAD_EINVAL;
   }
-  hipLaunchKernelGGL((kernel<BM, BN, true, 512, AOp, BOp, Epi, false>), dim3((int)G), dim3(512), 0, s, a, b, e, Mp, N, 0, 1, 0,
-                     (int)ntiles, 0, slab);
+  hipLaunchKernelGGL((kernel<BM, BN, true, 512, AOp, BOp, Epi, false>), dim3((int)G), dim3(512), 0, s, a, b, e, Mp, N,
+                     tn.stagger ? 1 : 0, 1, 0, (int)ntiles, 0, slab);
   if (stat) {
     if constexpr (HasStat<Epi>::value)
       hipLaunchKernelGGL((fixup_tile<BM, BN, Epi>), dim3((int)ntiles), dim3(256), 0, s, e, slab, Mp, N, 1, G, 0, (int)ntiles, cdiv(N, BN));

@@ -29,6 +29,7 @@ const OptName kOpts[] = {
     {"no_fused_stats", "AVVAD_NO_FUSED_STATS", &AvvadTune::no_fused_stats},
     {"no_cls", "AVVAD_NO_CLS", &AvvadTune::no_cls},
     {"cls_cap", "AVVAD_CLS_CAP", &AvvadTune::cls_cap},
+    {"stagger", "AVVAD_STAGGER", &AvvadTune::stagger},
     {"max_cus", "AVVAD_MAX_CUS", &AvvadTune::max_cus},
     {"bwd_max_cus", "AVVAD_BWD_MAX_CUS", &AvvadTune::bwd_max_cus},
 };
