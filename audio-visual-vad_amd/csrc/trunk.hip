@@ -756,8 +756,12 @@ static inline bool bf16_conv_ok(const Geom& g) {
          fits_buf((long)g.N * g.Ho * g.Wo * g.Co / 2) && fits_buf((long)g.KS * g.KS * g.C * g.Co / 2);
 }
 // position classes on the bf16 engine (the zero padding skipped: igemm.h); 64-channel chunks
+// (the bf16 kernels are bound by operand traffic, not by the matrix pipe: skipped products buy time only where they are 40 %
+//  of the tile -- the 3x3 grid -- and on larger grids the all-tiles-in-the-pool fix-up costs more than they save: measured
+//  per forward launch, 9x9 grid 55 -> 74 us, 5x5 66 -> 73 us, 3x3 78 -> 65 us)
 static inline bool cls16_common(const Geom& g, float* slab) {
-  return !avvad_tune().no_cls && slab && g.KS == 3 && g.pad == 1 && g.N >= 128 && g.Ho >= 2 && g.Wo >= 2 && avvad_tune().no_streamk == 0;
+  return !avvad_tune().no_cls && slab && g.KS == 3 && g.pad == 1 && g.N >= 128 && g.Ho >= 2 && g.Wo >= 2 && g.Ho * g.Wo <= 9 &&
+         avvad_tune().no_streamk == 0;
 }
 static inline bool conv_fwd16_cls_ok(const Geom& g, float* slab) {
   if (!cls16_common(g, slab) || g.Co < 128) return false;

@@ -1349,8 +1349,8 @@ def _load_bench():
     return bench
 
 
-@pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_full_size_c4_dp_shard_gradient_sum(dtype, lib_options):
+@pytest.mark.parametrize("dtype,whole_tiles", [("f32", False), ("f32", True), ("bf16", True)])
+def test_full_size_c4_dp_shard_gradient_sum(dtype, whole_tiles, lib_options):
     """BASELINE configs[3]/[4] per-GPU shard (64 sequences x 16 frames, W0 encoder, 2xLSTM1024): the data-parallel
     property on ONE GPU.  With BatchNorm in eval mode the summed-over-sequences loss makes
     grad(full batch) == grad(shard 0) + grad(shard 1) -- exactly what the SUM all-reduce relies on.  Every schedule is
@@ -1361,6 +1361,11 @@ def test_full_size_c4_dp_shard_gradient_sum(dtype, lib_options):
     from packages.models.AV_Net import DeepVAD_AV
     from packages.models.utils import batch_binary_cross_entropy
     bench = _load_bench()
+    # f32, production schedule: the stream-K split points (and, from 128 frames up, the position-class tiling) move with the
+    # batch size, so a sample's fp32 sums differ in ORDER between the full batch and its shards; a ReLU unit whose
+    # pre-activation sits within rounding of zero then lands on the other side and moves every gradient upstream of it by
+    # ~1e-3 (measured worst tensor 4e-4 .. 1.3e-3, always the stem / early trunk weights): bound 5e-3, a wrong shard sum is O(1).
+    # Whole-tile schedule: a sample's sums do not depend on its batch at all -- only the final sums over samples differ in order.
     if dtype == "bf16":
         lib_options("bf16", 1)
         # Rounding to bf16 is discontinuous: a 1e-7 difference in an fp32 sum (stream-K split points move with the batch size)
@@ -1368,6 +1373,7 @@ def test_full_size_c4_dp_shard_gradient_sum(dtype, lib_options):
         # two runs differ by the bf16 noise level itself (measured, tools/lab/shard_probe.py: trunk features 3.5e-3, deep
         # gradients 5-9 %).  Under the whole-tile schedule a sample's sums do not depend on the batch it sits in, the
         # bf16 roundings agree bit for bit and the shard-sum property is exact up to the fp32 order of the final sums.
+    if whole_tiles:
         lib_options("no_streamk", 1)
     torch.manual_seed(0)
     m = DeepVAD_AV(2, 1024, 1, wavenet_params=bench.W0).to(DEV).eval()
@@ -1394,8 +1400,9 @@ def test_full_size_c4_dp_shard_gradient_sum(dtype, lib_options):
                    zip([q for q in m.named_parameters() if not q[0].startswith("bn.")], gf, g0, g1)), reverse=True)
     print("worst tensors:", rels[:6])
     worst = rels[0][0]
-    print("DP shard-sum property (%s): loss %.4f = %.4f + %.4f, worst relL2 over %d tensors %.2e" % (dtype, lf, l0, l1, len(gf), worst))
-    assert worst < (1e-3 if dtype == "f32" else 2e-3)      # measured 4.0e-4 (f32): one tensor behind a flipped ReLU unit; a wrong shard sum is O(1)
+    print("DP shard-sum property (%s, %s schedule): loss %.4f = %.4f + %.4f, worst relL2 over %d tensors %.2e"
+          % (dtype, "whole-tile" if whole_tiles else "production", lf, l0, l1, len(gf), worst))
+    assert worst < (2e-3 if dtype == "bf16" else (1e-4 if whole_tiles else 5e-3))
 
 
 def test_bf16_benched_model_ragged_logits_vs_fp32_oracle(lib_options):
