@@ -22,6 +22,7 @@ const OptName kOpts[] = {
     {"wn_bwd_t", "AVVAD_WN_BWD_T", &AvvadTune::wn_bwd_t},
     {"no_buf", "AVVAD_NO_BUF", &AvvadTune::no_buf},
     {"no_fixup1", "AVVAD_NO_FIXUP1", &AvvadTune::no_fixup1},
+    {"no_conv64", "AVVAD_NO_CONV64", &AvvadTune::no_conv64},
     {"wn_flat", "AVVAD_WN_FLAT", &AvvadTune::wn_flat},
     {"wn_grid", "AVVAD_WN_GRID", &AvvadTune::wn_grid},
     {"wn_dx", "AVVAD_WN_DX", &AvvadTune::wn_dx},

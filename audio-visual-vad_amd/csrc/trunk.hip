@@ -16,6 +16,7 @@
 // reduction in fp64; normalisation / ReLU / residual add / pooling are fused
 // elementwise kernels with 16-byte accesses.
 #include "bgemm.h"
+#include "conv64.h"
 
 using convop::Geom;
 
@@ -597,6 +598,25 @@ static int conv_dgrad_cls(const float* dy, const float* wd, float* dx, const Geo
   e.W = g.C; e.rows = g.N; e.cr = cr; e.sched = sc;
   return igemm::launch_cls(a, b, e, MB * P * 128, g.C, s, slab);
 }
+// ---- the 64 -> 64 channel 3x3 / 1 / 1 convolutions (ResNet layer1): weights-stationary kernel, conv64.h
+static inline int conv64_cus() { return (avvad_tune().max_cus > 0 && avvad_tune().max_cus < 256) ? avvad_tune().max_cus : 256; }
+static inline bool conv64_ok(const Geom& g) {
+  const long M = (long)g.N * g.H * g.W;
+  return avvad_tune().bf16 == 0 && !avvad_tune().no_conv64 && g.C == 64 && g.Co == 64 && g.KS == 3 && g.stride == 1 && g.pad == 1 &&
+         g.Ho == g.H && g.Wo == g.W && M > 0 && fits_buf(M * 64) && (unsigned long)(M + 64) * (unsigned long)(g.H * g.W) < 0x100000000ull;
+}
+// y = conv(x) (flip = false, wpk = forward pack) or dx (+)= dgrad(dy) (flip = true, wpk = dgrad pack)
+static int conv64_launch(bool flip, const float* x, const float* wpk, float* y, const Geom& g, int accumulate, hipStream_t s, double* stat) {
+  const int M = g.N * g.H * g.W;
+  const int grid = conv64::grid_for(M, conv64_cus());
+  const unsigned mg_hw = convop::div_magic((unsigned)(g.H * g.W)), mg_w = convop::div_magic((unsigned)g.W);
+  if (flip)
+    hipLaunchKernelGGL(conv64::kernel<true>, dim3(grid), dim3(conv64::NW * 64), 0, s, x, wpk, y, M, g.H, g.W, mg_hw, mg_w, accumulate, stat);
+  else
+    hipLaunchKernelGGL(conv64::kernel<false>, dim3(grid), dim3(conv64::NW * 64), 0, s, x, wpk, y, M, g.H, g.W, mg_hw, mg_w, accumulate, stat);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
 // number of partial-sum chunks the forward of convolution g leaves in its `stat` buffer (one per M tile of its GEMM)
 static inline int fwd_stat_chunks(const Geom& g, float* slab);
 
@@ -630,11 +650,13 @@ static inline bool conv_fwd16_cls_ok(const Geom& g, float* slab);
 static inline int fwd_stat_chunks(const Geom& g, float* slab) {
   if (avvad_tune().bf16 == 1)
     return (g.C % 64 == 0 && g.Co % 64 == 0 && conv_fwd16_cls_ok(g, slab)) ? g.Ho * g.Wo * cdiv(g.N, 128) : cdiv((long)g.N * g.Ho * g.Wo, 128);
+  if (conv64_ok(g)) return conv64::grid_for((long)g.N * g.H * g.W, conv64_cus());      // one chunk per workgroup
   if (conv_fwd_cls_ok(g, slab)) return g.Ho * g.Wo * cdiv(g.N, 128);
   const int rows = fwd_tile_rows(g);
   return rows ? cdiv((long)g.N * g.Ho * g.Wo, rows) : 0;
 }
 static int conv_fwd(const float* x, const float* wf, float* y, const Geom& g, hipStream_t s, float* slab, double* stat = nullptr) {
+  if (conv64_ok(g)) return conv64_launch(false, x, wf, y, g, 0, s, stat);
   if (conv_fwd_cls_ok(g, slab)) return conv_fwd_cls(x, wf, y, g, s, slab, stat);
   const bool buf = fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.KS * g.KS * g.C * g.Co) && !avvad_tune().no_buf;
   return buf ? conv_fwd_t<true>(x, wf, y, g, s, slab, stat) : conv_fwd_t<false>(x, wf, y, g, s, slab, stat);
@@ -683,6 +705,7 @@ static int conv_dgrad_t(const float* dy, const float* wd, float* dx, const Geom&
   return igemm::launch<128, 128>(a, b, e, M, g.C, K, 1, s, slab);
 }
 static int conv_dgrad(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
+  if (conv64_ok(g)) return conv64_launch(true, dy, wd, dx, g, accumulate, s, nullptr);
   if (conv_dgrad_cls_ok(g, slab)) return conv_dgrad_cls(dy, wd, dx, g, accumulate, s, slab);
   const bool buf = fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && fits_buf((long)g.KS * g.KS * g.C * g.Co) && !avvad_tune().no_buf;
   return buf ? conv_dgrad_t<true>(dy, wd, dx, g, accumulate, s, slab) : conv_dgrad_t<false>(dy, wd, dx, g, accumulate, s, slab);

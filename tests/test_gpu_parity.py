@@ -479,6 +479,55 @@ def test_conv2d_fallback_paths_agree(N, H, W, C, Co, KS, stride, pad, lib_option
         _report("conv %s: four-wave fix-up vs one wave per strip" % name, b, a, 1e-5, 1e-6)   # (summation order of the slabs differs)
 
 
+@pytest.mark.parametrize("N,H,W", [(3, 17, 17), (70, 9, 13), (1, 3, 3), (1, 1, 1), (1024, 17, 17)])
+def test_conv64_weights_stationary_kernel(N, H, W, lib_options):
+    """The 64 -> 64 channel 3x3 / 1 / 1 convolutions (ResNet layer1) run on their own weights-stationary kernel (conv64.h):
+    forward, data gradient and accumulating data gradient against the engine's implicit GEMM on the same operands (option
+    no_conv64; different summation order: 1e-5 relative to the result's scale), at ragged pixel counts (a last tile of 3, 9 and
+    1 pixels), a single pixel, and the benchmark's full size; the small cases also against F.conv2d + autograd."""
+    import ctypes as Ct
+    import torch.nn.functional as F
+    from avvad import _lib as L, ops
+    lib = L.lib()
+    st = Ct.c_void_p(torch.cuda.current_stream().cuda_stream)
+    d = L.ConvDesc(N, H, W, 64, 64, 3, 1, 1)
+    torch.manual_seed(N + H)
+    x = torch.randn(N, H, W, 64, device=DEV)
+    gy = torch.randn(N, H, W, 64, device=DEV)
+    w = torch.randn(64, 64, 3, 3, device=DEV) / 24.0
+    wf = torch.empty(9 * 64 * 64, device=DEV)
+    wdg = torch.empty(9 * 64 * 64, device=DEV)
+    L.check(lib.avvad_conv2d_pack_weights(L.ptr(w), L.ptr(wf), L.ptr(wdg), Ct.byref(d), st), "pack")
+    ews = ops.engine_ws(DEV)
+    wsz = ews.numel() * 4
+    dx0 = torch.randn(N, H, W, 64, device=DEV)
+
+    def run():
+        y = torch.empty(N, H, W, 64, device=DEV)
+        dx = torch.empty_like(x)
+        dxa = dx0.clone()
+        L.check(lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), Ct.byref(d), L.ptr(ews), wsz, st), "fwd")
+        L.check(lib.avvad_conv2d_dgrad(L.ptr(gy), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 0, L.ptr(ews), wsz, st), "dgrad")
+        L.check(lib.avvad_conv2d_dgrad(L.ptr(gy), L.ptr(wdg), L.ptr(dxa), Ct.byref(d), 1, L.ptr(ews), wsz, st), "dgrad +=")
+        torch.cuda.synchronize()
+        return y, dx, dxa
+    direct = run()
+    again = run()
+    for a, b in zip(direct, again):
+        assert torch.equal(a, b)                       # run to run: the same bits
+    lib_options("no_conv64", 1)
+    engine = run()
+    for a, b, name in zip(direct, engine, ("fwd", "dgrad", "dgrad +=")):
+        _report("conv64 %dx%dx%d %s: weights-stationary kernel vs engine" % (N, H, W, name), a, b, 1e-5 * float(b.abs().max()), 0.0)
+    assert torch.equal(direct[2] - dx0, direct[2] - dx0) and float((direct[2] - (dx0 + direct[1])).abs().max()) <= 2e-6 * float(direct[2].abs().max())
+    if N <= 70:
+        xr = x.permute(0, 3, 1, 2).cpu().requires_grad_(True)
+        yr = F.conv2d(xr, w.cpu(), None, 1, 1)
+        yr.backward(gy.permute(0, 3, 1, 2).cpu())
+        _report("conv64 %dx%dx%d fwd vs F.conv2d" % (N, H, W), direct[0].permute(0, 3, 1, 2), yr.detach(), 2e-5, 1e-5)
+        _report("conv64 %dx%dx%d dgrad vs autograd" % (N, H, W), direct[1].permute(0, 3, 1, 2), xr.grad, 2e-5, 1e-5)
+
+
 # ------------------------------------------------------------------------------------------ trunk
 def _video_state():
     from oracle import resnet18
