@@ -47,6 +47,7 @@ struct AvvadTune {
   int cls_cap;              // tuning aid: most tiles a position-class product may have (0 = two per CU)
   int no_cls;               // 3x3 convolutions without the position-class schedule (zero padding multiplied like everything else)
   int no_fused_stats;       // BatchNorm batch statistics by the separate column-reduction pass instead of the convolution's epilogue
+  int no_s2_cls;            // stride-2 data gradients as four accumulating parity-class launches instead of one position-class product
   int no_conv64;            // the 64 -> 64 channel 3x3 convolutions on the engine instead of the weights-stationary kernel (conv64.h)
   int bwd_max_cus;          // the same cap, applied to the BACKWARD entry points only (that is when the gradient all-reduce runs)
   int max_cus;              // cap on the CUs a persistent grid occupies (0 = all 256): leaves room for RCCL kernels

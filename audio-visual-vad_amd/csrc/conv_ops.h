@@ -315,8 +315,8 @@ __device__ __forceinline__ void cls_tap(const igemm::ClassTile& t, int k0, int& 
   const int q = k0 >> 5, ab = t.a * t.b;
   cc = igemm::dev_div(q, t.mg_ab);
   const int j = q - cc * ab, dkh = igemm::dev_div(j, t.mg_b);
-  kh = t.kh_lo + dkh;
-  kw = t.kw_lo + (j - dkh * t.b);
+  kh = t.kh_lo + dkh * t.step;
+  kw = t.kw_lo + (j - dkh * t.b) * t.step;
 }
 // forward A: classes = OUTPUT positions (ho, wo); row n of class p reads x[n, ho s - 1 + kh, wo s - 1 + kw, :]
 struct Im2colFwdCls {
@@ -350,7 +350,8 @@ struct Im2colFwdCls {
     fetch4<true>(x, c.ok ? c.boff + soff : INVALID_OFF(true), v);
   }
 };
-// data gradient A (stride 1): classes = INPUT positions (hi, wi); row n of class p reads dy[n, hi + 1 - kh, wi + 1 - kw, :]
+// data gradient A: classes = INPUT positions (hi, wi); row n of class p reads dy[n, (hi + 1 - kh) / s, (wi + 1 - kw) / s, :]
+// (stride 2: the schedule's live taps are exactly those for which the quotient is whole and inside dy, ClassSched::s2)
 struct Im2colDgradCls {
   static constexpr bool KCONTIG = true;
   static constexpr int VEC = 4;
@@ -377,7 +378,8 @@ struct Im2colDgradCls {
   __device__ __forceinline__ void load(const Ctx& c, const igemm::ClassTile& t, int, int k0, int, float* v) const {
     int cc, kh, kw;
     cls_tap(t, k0, cc, kh, kw);
-    const int ho = t.ho + g.pad - kh, wo = t.wo + g.pad - kw;
+    const int sh = g.stride == 2 ? 1 : 0;
+    const int ho = (t.ho + g.pad - kh) >> sh, wo = (t.wo + g.pad - kw) >> sh;
     const unsigned soff = ((unsigned)(ho * g.Wo + wo) * (unsigned)g.Co + (unsigned)cc * 32u) * 4u;
     fetch4<true>(dy, c.ok ? c.boff + soff : INVALID_OFF(true), v);
   }

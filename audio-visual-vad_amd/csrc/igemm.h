@@ -70,10 +70,17 @@ struct ClassSched {
   // L2 (position-outermost order re-fetched every image once per position from beyond L2: 427 MB per launch, PMC).
   int Ho, Wo, ntn, nchunk, MB;    // grid of position classes; N tiles; channel chunks per tap; image blocks (of 128)
   int KS, fsh, lsh, fsw, lsw;     // first / last row (column) of the grid loses fsh / lsh (fsw / lsw) taps
-  __host__ __device__ int ah(int h) const { return KS - (h == 0 ? fsh : 0) - (h == Ho - 1 ? lsh : 0); }
-  __host__ __device__ int bw(int w) const { return KS - (w == 0 ? fsw : 0) - (w == Wo - 1 ? lsw : 0); }
-  __host__ __device__ int Ah(int h) const { return KS * h - (h > 0 ? fsh : 0) - (h > Ho - 1 ? lsh : 0); }   // sum of ah below h
-  __host__ __device__ int Bw(int w) const { return KS * w - (w > 0 ? fsw : 0) - (w > Wo - 1 ? lsw : 0); }
+  // s2: the data gradient of a 3x3 / STRIDE 2 / pad 1 convolution.  The classes are the INPUT positions (h, w) of a grid
+  // Ho x Wo = H x W whose gradient image dy is Hq x Wq: row h is reached by the taps kh with h + 1 - kh even and
+  // (h + 1 - kh) / 2 < Hq -- kh = 1 for even h, kh = 0 and 2 for odd h (kh = 0 only while (h + 1) / 2 < Hq): 1, 2, 1, 2, ...
+  // live tap rows instead of 3, i.e. the four parity classes of the decomposition with 1 / 2 / 2 / 4 taps, in ONE product.
+  int s2 = 0, Hq = 0, Wq = 0;
+  __host__ __device__ static int odd2(int h, int q) { return ((h & 1) && ((h + 1) >> 1) < q) ? 1 : 0; }
+  __host__ __device__ static int cnt2(int h, int q) { const int m = h >> 1; return h + (m < q - 1 ? m : q - 1); }   // sum of (1 + odd2) below h
+  __host__ __device__ int ah(int h) const { return s2 ? 1 + odd2(h, Hq) : KS - (h == 0 ? fsh : 0) - (h == Ho - 1 ? lsh : 0); }
+  __host__ __device__ int bw(int w) const { return s2 ? 1 + odd2(w, Wq) : KS - (w == 0 ? fsw : 0) - (w == Wo - 1 ? lsw : 0); }
+  __host__ __device__ int Ah(int h) const { return s2 ? cnt2(h, Hq) : KS * h - (h > 0 ? fsh : 0) - (h > Ho - 1 ? lsh : 0); }   // sum of ah below h
+  __host__ __device__ int Bw(int w) const { return s2 ? cnt2(w, Wq) : KS * w - (w > 0 ? fsw : 0) - (w > Wo - 1 ? lsw : 0); }
   __host__ __device__ long per_block() const { return (long)nchunk * ntn * Ah(Ho) * Bw(Wo); }
   __host__ __device__ long total() const { return per_block() * MB; }
   __host__ __device__ int len(int tile) const {
@@ -117,6 +124,7 @@ struct ClassRow {
 struct ClassTile {
   int ho, wo, a, b, kh_lo, kw_lo;
   unsigned mg_ab, mg_b;           // exact-division magics for a * b and b
+  int step;                       // live taps are kh_lo, kh_lo + step, ...: 1, or 2 for the stride-2 data gradient
 };
 __device__ __forceinline__ unsigned dev_magic(int d) { return d <= 1 ? 0u : (unsigned)(0x100000000ull / (unsigned)d) + 1u; }
 __device__ __forceinline__ int dev_div(int k, unsigned mg) { return mg ? (int)__umulhi((unsigned)k, mg) : k; }
@@ -131,6 +139,12 @@ __device__ __forceinline__ ClassTile class_tile(const ClassSched& s, int p, bool
   const int cut_w = flip ? (t.wo == s.Wo - 1 ? s.lsw : 0) : (t.wo == 0 ? s.fsw : 0);
   t.kh_lo = cut_h;
   t.kw_lo = cut_w;
+  t.step = 1;
+  if (s.s2) {      // even position: the middle tap; odd: taps 0 and 2 (2 alone in a last row that tap 0 would take past dy)
+    t.kh_lo = (t.ho & 1) ? (t.a == 2 ? 0 : 2) : 1;
+    t.kw_lo = (t.wo & 1) ? (t.b == 2 ? 0 : 2) : 1;
+    t.step = 2;
+  }
   t.mg_ab = dev_magic(t.a * t.b);
   t.mg_b = dev_magic(t.b);
   return t;

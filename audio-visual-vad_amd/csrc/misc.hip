@@ -23,6 +23,7 @@ const OptName kOpts[] = {
     {"no_buf", "AVVAD_NO_BUF", &AvvadTune::no_buf},
     {"no_fixup1", "AVVAD_NO_FIXUP1", &AvvadTune::no_fixup1},
     {"no_conv64", "AVVAD_NO_CONV64", &AvvadTune::no_conv64},
+    {"no_s2_cls", "AVVAD_NO_S2_CLS", &AvvadTune::no_s2_cls},
     {"wn_flat", "AVVAD_WN_FLAT", &AvvadTune::wn_flat},
     {"wn_grid", "AVVAD_WN_GRID", &AvvadTune::wn_grid},
     {"wn_dx", "AVVAD_WN_DX", &AvvadTune::wn_dx},

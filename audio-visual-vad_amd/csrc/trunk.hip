@@ -572,7 +572,9 @@ static inline bool conv_fwd_cls_ok(const Geom& g, float* slab) {
          fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf(9L * g.C * g.Co);
 }
 static inline bool conv_dgrad_cls_ok(const Geom& g, float* slab) {
-  if (!cls_common(g, slab) || g.stride != 1 || g.C % 4 || g.C < 128) return false;
+  // (stride 2: the parity classes as position classes of ONE product, igemm::ClassSched::s2, instead of four accumulating launches
+  //  over a zero-filled dx; option no_s2_cls keeps the four launches)
+  if (!cls_common(g, slab) || (g.stride != 1 && (g.stride != 2 || avvad_tune().no_s2_cls)) || g.C % 4 || g.C < 128) return false;
   const long tiles = (long)g.H * g.W * cdiv(g.N, 128) * cdiv(g.C, 128);
   return tiles <= cls_tile_cap() &&
          fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && fits_buf(9L * g.C * g.Co);
@@ -590,7 +592,8 @@ static int conv_fwd_cls(const float* x, const float* wf, float* y, const Geom& g
 }
 static int conv_dgrad_cls(const float* dy, const float* wd, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
   const int MB = cdiv(g.N, 128), P = g.H * g.W;
-  const igemm::ClassSched sc{g.H, g.W, cdiv(g.C, 128), g.Co / 32, MB, 3, 1, 1, 1, 1};
+  igemm::ClassSched sc{g.H, g.W, cdiv(g.C, 128), g.Co / 32, MB, 3, 1, 1, 1, 1};
+  if (g.stride == 2) { sc.s2 = 1; sc.Hq = g.Ho; sc.Wq = g.Wo; }
   const igemm::ClassRow cr{P, convop::div_magic(P)};
   convop::Im2colDgradCls a{dy, g, g.N, cr, sc};
   convop::ColTapRowsCls b{wd, g.C, g.C, g.Co, 3, 1, cr, sc};

@@ -1492,14 +1492,17 @@ def test_bf16_benched_model_ragged_logits_vs_fp32_oracle(lib_options):
 
 
 @pytest.mark.parametrize("N,H,W,C,Co,stride", [(200, 5, 5, 256, 256, 1), (130, 3, 3, 512, 512, 1), (256, 9, 9, 128, 256, 2),
-                                               (128, 5, 5, 256, 512, 2), (300, 3, 3, 256, 128, 1), (1024, 3, 3, 512, 512, 1)])
+                                               (128, 5, 5, 256, 512, 2), (300, 3, 3, 256, 128, 1), (1024, 3, 3, 512, 512, 1),
+                                               (130, 6, 8, 128, 128, 2), (200, 9, 5, 256, 128, 2)])
 def test_conv2d_position_classes_skip_the_zero_padding(N, H, W, C, Co, stride, lib_options):
     """3x3 / pad 1 convolutions whose tile count fits the stream-K pool run position-major (igemm.h "position classes"): a
     tile's rows share one grid position, its K loop walks only the taps that fall inside the image -- on a 3x3 grid 40 % of
     the products are multiplications by the zero padding; the weight gradient runs tap-major and contracts, per tap, only the
     grid positions at which that tap is inside the image.  Forward, data and weight gradient against torch's conv2d (same
     bounds as the dense schedule), with image counts that are not whole tiles (padded class rows), both strides; the skipped products
-    are exact zeros, so the dense schedule (option no_cls) must agree to the last bits of the fp32 summation order."""
+    are exact zeros, so the dense schedule (option no_cls) must agree to the last bits of the fp32 summation order.
+    Stride 2: the data gradient's four parity classes (1 / 2 / 2 / 4 live taps) are position classes of ONE product
+    (ClassSched::s2) -- odd and even grids, the even ones ending in a row that only tap 2 reaches."""
     import ctypes as Ct
     import torch.nn.functional as F
     from avvad import _lib as L, ops
