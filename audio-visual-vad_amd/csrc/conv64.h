@@ -36,13 +36,6 @@ __global__ void __launch_bounds__(NW * 64, 2)
   __shared__ __attribute__((aligned(16))) float wl[WROWS * 64 + NW * 64 * 4];     // weights + the statistics exchange (doubles)
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  {  // the weight image, verbatim
-    const float4* src = reinterpret_cast<const float4*>(wpk);
-    float4* dst = reinterpret_cast<float4*>(wl);
-#pragma unroll 6
-    for (int i = t; i < WROWS * 16; i += NW * 64) dst[i] = src[i];
-  }
-  __syncthreads();
   const __amdgpu_buffer_rsrc_t rx = brsrc2g(x);
   const __amdgpu_buffer_rsrc_t ry = brsrc2g(y);
   const long T = ((long)M + 31) / 32, G = gridDim.x;
@@ -107,6 +100,13 @@ __global__ void __launch_bounds__(NW * 64, 2)
     tile_ctx(tile);
     fetch(a0, 0);
   }
+  {  // the weight image, verbatim (the first tap's pieces are already in flight)
+    const float4* src = reinterpret_cast<const float4*>(wpk);
+    float4* dst = reinterpret_cast<float4*>(wl);
+#pragma unroll 6
+    for (int i = t; i < WROWS * 16; i += NW * 64) dst[i] = src[i];
+  }
+  __syncthreads();
   for (; tile < t_hi; tile += NW) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -183,6 +183,120 @@ __global__ void __launch_bounds__(NW * 64, 2)
       stat[((long)blockIdx.x * 2 + 1) * 64 + t] = sb;
     }
   }
+}
+
+// ---------------------------------------------------------------- the weight gradient of the same convolutions
+// dW[(kh, kw, c)][co] = sum over pixels of x[n, h + kh - 1, w + kw - 1, c] . dy[n, h, w, co]: a 576 x 64 output contracted over
+// ~300 k pixels.  On the engine this is 4.5 row tiles of 128 (10 % of the last one's work multiplies nothing) cut 100 ways
+// along K, each cut staging its own copies of x through LDS once PER TAP; 59 % of the fp32 MFMA peak.  Here the output is
+// stationary: a workgroup of 12 waves holds ALL 36 blocks of 32 x 32 in registers -- wave (quadrant (c half, co half), kh)
+// owns the three kw blocks -- and walks a contiguous range of image rows.  Per image row the three x rows it touches and the
+// dy row go through LDS ONCE (16-byte loads, double-buffered, one barrier per row; zero columns either side and zero rows
+// outside the image stand in for the padding) and serve all nine taps: lane (i, h) reads A[c = i][k = pixel w + h] and
+// B[k][co = j] as single conflict-free dwords.  Each workgroup leaves one partial [576][64]; a second kernel adds the
+// partials in workgroup order (bit-reproducible, no atomics).
+constexpr int WG_WAVES = 12;
+constexpr int WG_MAXW = 18;           // widest grid row the static LDS image holds
+constexpr int WG_PART = WROWS * 64;   // floats per partial
+
+__global__ void __launch_bounds__(WG_WAVES * 64, 3)
+    wgrad_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ part, const int NR, const int H,
+                 const int W, const unsigned mg_H) {
+  constexpr int XP = (WG_MAXW + 2) * 64;            // floats per staged x row (pitch), columns -1 .. W
+  constexpr int DP = (WG_MAXW + 2) * 64;            // floats per staged dy row (an even number of pixels + spare)
+  __shared__ __attribute__((aligned(16))) float lds[2 * (3 * XP + DP)];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int q = wave / 3, kh = wave - q * 3, cb = q >> 1, nb = q & 1;
+  for (int i = t; i < 2 * (3 * XP + DP) / 4; i += WG_WAVES * 64) reinterpret_cast<float4*>(lds)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const __amdgpu_buffer_rsrc_t rx = brsrc2g(x);
+  const __amdgpu_buffer_rsrc_t rd = brsrc2g(dy);
+  const long G = gridDim.x;
+  const int r_lo = (int)(blockIdx.x * (long)NR / G), r_hi = (int)((blockIdx.x + 1) * (long)NR / G);
+  // this thread's two staging items (the same for every row): item = (source row 0..2 of x | 3 = dy, pixel, 16-byte piece)
+  const int per_row = W * 16, items = 4 * per_row;
+  int sel[2], goff[2], loff[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int idx = t + u * WG_WAVES * 64;
+    const int rs = idx / per_row, rem = idx - rs * per_row, px = rem >> 4, c4 = rem & 15;
+    sel[u] = idx < items ? rs : -1;
+    goff[u] = ((rs < 3 ? rs - 1 : 0) * W + px) * 256 + c4 * 16;           // bytes, relative to the output row's first pixel
+    loff[u] = rs < 3 ? rs * XP + (px + 1) * 64 + c4 * 4 : 3 * XP + px * 64 + c4 * 4;
+  }
+  f4v st[2];
+  auto fetch = [&](int r) {
+    const int n = mg_H ? (int)__umulhi((unsigned)r, mg_H) : r, h = r - n * H;
+    const int rb = r * W * 256;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bool ok = sel[u] == 3 || (sel[u] >= 0 && (unsigned)(h + sel[u] - 1) < (unsigned)H);
+      const int vo = ok ? rb + goff[u] : BUF_OOB;
+      st[u] = sel[u] == 3 ? bload4(rd, vo, 0) : bload4(rx, vo, 0);
+    }
+  };
+  auto put = [&](int buf) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+      if (sel[u] >= 0) *reinterpret_cast<f4v*>(lds + buf * (3 * XP + DP) + loff[u]) = st[u];
+  };
+  f32x16 acc[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[k][r] = 0.f;
+  const int nks = (W + 1) >> 1;
+  __syncthreads();
+  if (r_lo < r_hi) {
+    fetch(r_lo);
+    put(0);
+  }
+  __syncthreads();
+  for (int r = r_lo; r < r_hi; ++r) {
+    const int buf = (r - r_lo) & 1;
+    if (r + 1 < r_hi) fetch(r + 1);
+    const float* const ap = lds + buf * (3 * XP + DP) + kh * XP + lh * 64 + cb * 32 + li;      // column w + h + kw (image column + 1)
+    const float* const bp = lds + buf * (3 * XP + DP) + 3 * XP + lh * 64 + nb * 32 + li;
+#pragma unroll 3
+    for (int ks = 0; ks < nks; ++ks) {
+      const float b = bp[ks * 128];
+      const float a0 = ap[ks * 128], a1 = ap[ks * 128 + 64], a2 = ap[ks * 128 + 128];
+      acc[0] = mfma32(a0, b, acc[0]);
+      acc[1] = mfma32(a1, b, acc[1]);
+      acc[2] = mfma32(a2, b, acc[2]);
+    }
+    if (r + 1 < r_hi) put(buf ^ 1);
+    __syncthreads();
+  }
+  float* const P = part + (long)blockIdx.x * WG_PART;
+#pragma unroll
+  for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      P[((kh * 3 + kw) * 64 + cb * 32 + mfma32_row(r, lh)) * 64 + nb * 32 + li] = acc[kw][r];
+}
+
+// out[e] = sum over workgroups b of part[b][e], in ascending b within four interleaved groups that meet in a fixed order
+__global__ void __launch_bounds__(256)
+    wgrad_reduce(const float* __restrict__ part, const int G, float* __restrict__ out) {
+  __shared__ float4 red[3][64];
+  const int c = threadIdx.x & 63, gq = threadIdx.x >> 6;
+  const long e4 = (long)blockIdx.x * 64 + c;                      // float4 index inside a partial
+  const float4* p = reinterpret_cast<const float4*>(part) + e4;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int b = gq; b < G; b += 32) {
+    float4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (b + 4 * u < G) ? p[(long)(b + 4 * u) * (WG_PART / 4)] : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w; }
+  }
+  if (gq > 0) red[gq - 1][c] = s;
+  __syncthreads();
+  if (gq > 0) return;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) { const float4 o = red[w][c]; s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w; }
+  reinterpret_cast<float4*>(out)[e4] = s;
 }
 
 // workgroups of a launch over M pixels (= chunks of the fused statistics): one per CU, fewer when there is less than a tile each

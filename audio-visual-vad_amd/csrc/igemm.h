@@ -1153,7 +1153,9 @@ constexpr int NUM_CU = 256;  // MI355X
 
 // Floats of slab workspace a launch may need: one BM x BN tile per persistent worker (512 x 128x128 = 1024 x 128x64 =
 // 1536 x 64x64 at most).  Callers carve this out of their own workspace (the C ABI's caller-allocates rule).
-constexpr size_t SLAB_FLOATS = (size_t)512 * 128 * 128;
+// (... or one [576][64] weight-gradient partial per CU, conv64.h: 256 x 36864, the larger of the two)
+constexpr size_t SLAB_FLOATS = (size_t)256 * 576 * 64;
+static_assert(SLAB_FLOATS >= (size_t)512 * 128 * 128, "one 128x128 tile per persistent worker");
 
 // split_k_hint > 1 marks a "few tiles, very long K" product (the conv weight gradients); with the K-major tuning option
 // it is cut K-major (see the kernel); everything else is scheduled as data-parallel rounds + one stream-K round.

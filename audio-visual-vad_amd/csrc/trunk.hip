@@ -766,7 +766,22 @@ static int conv_wgrad_tap(const float* x, const float* dy, float* pk, const Geom
   e.Mrows = M; e.sched = sc;
   return igemm::launch_cls(a, b, e, M, g.Co, s, slab);
 }
+// the 64 -> 64 channel 3x3 convolutions: output-stationary kernel + ordered reduction of the per-CU partials (conv64.h)
+static inline bool conv64_wgrad_ok(const Geom& g, float* slab) {
+  return conv64_ok(g) && slab && g.W <= conv64::WG_MAXW && (size_t)conv64_cus() * conv64::WG_PART <= igemm::SLAB_FLOATS &&
+         (long)g.N * g.H * g.W * 256 < (1L << 31);
+}
+static int conv64_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s, float* slab) {
+  const int NR = g.N * g.H;
+  const int grid = NR < conv64_cus() ? NR : conv64_cus();
+  hipLaunchKernelGGL(conv64::wgrad_kernel, dim3(grid), dim3(conv64::WG_WAVES * 64), 0, s, x, dy, slab, NR, g.H, g.W,
+                     convop::div_magic((unsigned)g.H));
+  hipLaunchKernelGGL(conv64::wgrad_reduce, dim3(conv64::WG_PART / 256), dim3(256), 0, s, (const float*)slab, grid, pk);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
 static int conv_wgrad(const float* x, const float* dy, float* pk, const Geom& g, hipStream_t s, float* slab) {
+  if (conv64_wgrad_ok(g, slab)) return conv64_wgrad(x, dy, pk, g, s, slab);
   if (conv_wgrad_tap_ok(g, slab)) return conv_wgrad_tap(x, dy, pk, g, s, slab);
   const bool buf = g.C > 1 && fits_buf((long)g.N * g.H * g.W * g.C) && fits_buf((long)g.N * g.Ho * g.Wo * g.Co) && !avvad_tune().no_buf;
   return buf ? conv_wgrad_t<true>(x, dy, pk, g, s, slab) : conv_wgrad_t<false>(x, dy, pk, g, s, slab);

@@ -482,7 +482,8 @@ def test_conv2d_fallback_paths_agree(N, H, W, C, Co, KS, stride, pad, lib_option
 @pytest.mark.parametrize("N,H,W", [(3, 17, 17), (70, 9, 13), (1, 3, 3), (1, 1, 1), (1024, 17, 17)])
 def test_conv64_weights_stationary_kernel(N, H, W, lib_options):
     """The 64 -> 64 channel 3x3 / 1 / 1 convolutions (ResNet layer1) run on their own weights-stationary kernel (conv64.h):
-    forward, data gradient and accumulating data gradient against the engine's implicit GEMM on the same operands (option
+    forward, data gradient, accumulating data gradient and weight gradient (output-stationary kernel + ordered reduction of the
+    per-CU partials) against the engine's implicit GEMM on the same operands (option
     no_conv64; different summation order: 1e-5 relative to the result's scale), at ragged pixel counts (a last tile of 3, 9 and
     1 pixels), a single pixel, and the benchmark's full size; the small cases also against F.conv2d + autograd."""
     import ctypes as Ct
@@ -509,15 +510,17 @@ def test_conv64_weights_stationary_kernel(N, H, W, lib_options):
         L.check(lib.avvad_conv2d_fwd(L.ptr(x), L.ptr(wf), L.ptr(y), Ct.byref(d), L.ptr(ews), wsz, st), "fwd")
         L.check(lib.avvad_conv2d_dgrad(L.ptr(gy), L.ptr(wdg), L.ptr(dx), Ct.byref(d), 0, L.ptr(ews), wsz, st), "dgrad")
         L.check(lib.avvad_conv2d_dgrad(L.ptr(gy), L.ptr(wdg), L.ptr(dxa), Ct.byref(d), 1, L.ptr(ews), wsz, st), "dgrad +=")
+        dw = torch.full((9 * 64, 64), float("nan"), device=DEV)
+        L.check(lib.avvad_conv2d_wgrad(L.ptr(x), L.ptr(gy), L.ptr(dw), Ct.byref(d), L.ptr(ews), wsz, st), "wgrad")
         torch.cuda.synchronize()
-        return y, dx, dxa
+        return y, dx, dxa, dw
     direct = run()
     again = run()
     for a, b in zip(direct, again):
         assert torch.equal(a, b)                       # run to run: the same bits
     lib_options("no_conv64", 1)
     engine = run()
-    for a, b, name in zip(direct, engine, ("fwd", "dgrad", "dgrad +=")):
+    for a, b, name in zip(direct, engine, ("fwd", "dgrad", "dgrad +=", "wgrad")):
         _report("conv64 %dx%dx%d %s: weights-stationary kernel vs engine" % (N, H, W, name), a, b, 1e-5 * float(b.abs().max()), 0.0)
     assert torch.equal(direct[2] - dx0, direct[2] - dx0) and float((direct[2] - (dx0 + direct[1])).abs().max()) <= 2e-6 * float(direct[2].abs().max())
     if N <= 70:
@@ -526,6 +529,9 @@ def test_conv64_weights_stationary_kernel(N, H, W, lib_options):
         yr.backward(gy.permute(0, 3, 1, 2).cpu())
         _report("conv64 %dx%dx%d fwd vs F.conv2d" % (N, H, W), direct[0].permute(0, 3, 1, 2), yr.detach(), 2e-5, 1e-5)
         _report("conv64 %dx%dx%d dgrad vs autograd" % (N, H, W), direct[1].permute(0, 3, 1, 2), xr.grad, 2e-5, 1e-5)
+        wr = w.cpu().requires_grad_(True)
+        F.conv2d(x.permute(0, 3, 1, 2).cpu(), wr, None, 1, 1).backward(gy.permute(0, 3, 1, 2).cpu())
+        _report("conv64 %dx%dx%d wgrad vs autograd" % (N, H, W), direct[3], wr.grad.permute(2, 3, 1, 0).reshape(9 * 64, 64), 1e-4, 1e-5)
 
 
 # ------------------------------------------------------------------------------------------ trunk
