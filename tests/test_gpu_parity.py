@@ -927,7 +927,8 @@ def test_bf16_convolutions_vs_rounded_operands(N, H, W, C, Co, KS, stride, pad, 
 @pytest.mark.parametrize("N,H,W,C,Co,KS,stride,pad", [(3, 17, 17, 64, 64, 3, 1, 1), (2, 17, 17, 64, 128, 3, 2, 1), (5, 9, 9, 128, 128, 3, 1, 1),
                                                       (2, 17, 17, 64, 128, 1, 2, 0), (4, 3, 3, 512, 512, 3, 1, 1), (700, 9, 9, 128, 128, 3, 1, 1),
                                                       (300, 5, 5, 256, 256, 3, 1, 1), (96, 9, 9, 128, 256, 3, 2, 1), (40, 17, 17, 64, 64, 3, 1, 1),
-                                                      (130, 3, 3, 512, 512, 3, 1, 1), (256, 9, 9, 128, 256, 3, 2, 1), (200, 5, 5, 256, 512, 3, 2, 1)])
+                                                      (130, 3, 3, 512, 512, 3, 1, 1), (256, 9, 9, 128, 256, 3, 2, 1), (200, 5, 5, 256, 512, 3, 2, 1),
+                                                      (333, 9, 9, 128, 256, 3, 1, 1)])
 def test_bf16_data_path_convolutions(N, H, W, C, Co, KS, stride, pad):
     """The bf16 DATA PATH's convolutions (csrc/bgemm.h; what the trunk runs under option bf16 = 1): operands are bf16 in
     memory -- NHWC bf16 activations / output gradients, K-contiguous bf16 weight packs -- staged with 16-byte loads, the
