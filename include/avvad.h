@@ -60,7 +60,9 @@ int avvad_abi_version(void);
  *   training), "bwd_max_cus" (the same cap applied only while a backward entry point runs: the gradient all-reduce overlaps
  *   the backward pass, the forward keeps the whole chip), "no_cls" (1 = 3x3 convolutions multiply their zero padding like
  *   everything else instead of running position-major), "cls_cap", "no_fused_stats" (1 = BatchNorm statistics by separate
- *   column-reduction passes instead of the producing kernels' epilogues).
+ *   column-reduction passes instead of the producing kernels' epilogues), "no_conv64" (1 = the 64 -> 64 channel 3x3
+ *   convolutions on the GEMM engine instead of their weights-stationary / output-stationary kernels), "no_s2_cls" (1 = a
+ *   stride-2 data gradient as four accumulating parity-class launches instead of one position-class product).
  * Initial values come from AVVAD_<NAME> in the environment, read once.  Returns AVVAD_EINVAL for an unknown name. */
 int avvad_set_option(const char* name, int value);
 int avvad_get_option(const char* name);
@@ -83,7 +85,8 @@ typedef struct {
   int relu_a;  /* apply max(.,0) to A elements on load */
   int relu_b;
 } avvad_gemm_desc;
-/* Scratch of the GEMM engine, bytes (a constant: one tile per persistent worker).  Tiles whose K range is cut between
+/* Scratch of the GEMM engine, bytes (a constant: one tile per persistent worker, or -- the larger -- one [576][64] partial
+ * weight gradient per CU for the 64-channel convolutions' own kernel).  Tiles whose K range is cut between
  * workers (the engine's stream-K round) leave their partial sums there and a fix-up kernel adds them in a fixed
  * order: results are bit-reproducible run to run, there are no float atomics.  Every entry point that runs a single
  * GEMM / convolution takes (ws, ws_bytes); ws == NULL (or too small) selects whole-tile scheduling -- same results up
