@@ -518,6 +518,14 @@ def test_conv64_weights_stationary_kernel(N, H, W, lib_options):
     again = run()
     for a, b in zip(direct, again):
         assert torch.equal(a, b)                       # run to run: the same bits
+    # a capped grid (option max_cus: what a data-parallel rank's backward runs under) deals the same tiles to fewer workgroups:
+    # forward / data gradient bit for bit, the weight gradient up to the grouping of its per-workgroup partials
+    lib_options("max_cus", 200)
+    capped = run()
+    lib_options("max_cus", 0)
+    for a, b in zip(direct[:3], capped[:3]):
+        assert torch.equal(a, b)
+    assert _max_rel(direct[3], capped[3]) < 1e-5
     lib_options("no_conv64", 1)
     engine = run()
     for a, b, name in zip(direct, engine, ("fwd", "dgrad", "dgrad +=", "wgrad")):
