@@ -29,17 +29,20 @@ def main():
     red = avd.BucketReducer(opt.params, opt.flat_grad, opt.offsets, bucket_bytes=1 << 20,   # several buckets, cut at sub-modules
                             names=[n_ for n_, p_ in model.named_parameters() if p_.requires_grad], min_group_bytes=1 << 12)
     lengths_s, wave_s, video_s, target_s = avd.shard_batch([lengths, wave, video, target], rank, world)
+    first = None
     for step in range(2):                                # two steps: the reducer's per-step bookkeeping is reset in between
         y = model(wave_s, video_s, lengths_s)
         loss = batch_binary_cross_entropy(y, target_s, lengths_s, 1e-8)
         loss.backward()
         red.finish()
         if step == 0:
+            torch.cuda.synchronize()
+            first = opt.flat_grad.detach().cpu().clone()
             opt.flat.add_(opt.flat_grad, alpha=-case.SGD_LR)      # plain SGD (Adam would amplify 1e-7 differences to +-lr)
             opt.zero_grad()
     torch.cuda.synchronize()
     if rank == 0:
-        torch.save(opt.flat_grad.detach().cpu(), out)
+        torch.save({"step0": first, "step1": opt.flat_grad.detach().cpu()}, out)
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 

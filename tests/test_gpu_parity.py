@@ -1657,13 +1657,19 @@ def test_two_rank_gpu_data_parallel_step(tmp_path, lib_options, monkeypatch, ove
     model = case.make_model().to(DEV).eval()
     wave, video, target, lengths = [t.to(DEV) for t in case.make_batch()]
     opt = FlatAdam(model.parameters(), lr=1e-3)
+    refs = []
     for step in range(2):                                # the same two steps (one SGD update in between) on the whole batch
         loss = batch_binary_cross_entropy(model(wave, video, lengths), target, lengths, 1e-8)
         loss.backward()
+        refs.append(opt.flat_grad.detach().cpu().clone())
         if step == 0:
             opt.flat.add_(opt.flat_grad, alpha=-case.SGD_LR)
             opt.zero_grad()
-    ref = opt.flat_grad.detach().cpu()
-    rel = float((got - ref).norm() / ref.norm())
-    print("two-rank DP: |flat grad| %.4e, relL2(all-reduced shards vs whole batch) %.2e" % (float(ref.norm()), rel))
-    assert float(ref.norm()) > 0 and rel < 1e-4      # second-step gradients; only the order of the sum over samples differs
+    rel0 = float((got["step0"] - refs[0]).norm() / refs[0].norm())
+    rel1 = float((got["step1"] - refs[1]).norm() / refs[1].norm())
+    print("two-rank DP: |flat grad| %.4e, relL2(all-reduced shards vs whole batch) step 1: %.2e, step 2: %.2e" % (float(refs[1].norm()), rel0, rel1))
+    # First step: the forward is bit-identical on both sides, only the order of the sum over samples differs: 1e-5.
+    # Second step: its weights carry the first step's 1e-7 differences, and ONE ReLU unit of this small model that sits on a
+    # zero crossing may then decide differently -- measured once (under a CU cap, tools/lab/dp_two_rank_probe.py): 5e-4, every
+    # tensor upstream of one layer-2 unit off by ~1e-3.  A reducer fault (a bucket reduced early, twice or not at all) is O(0.1+).
+    assert float(refs[0].norm()) > 0 and rel0 < 1e-5 and rel1 < 5e-3
