@@ -842,6 +842,20 @@ static int conv_dgrad16(const float* dy16, const float* wd16, float* dx, const G
   const int M = g.N * g.H * g.W, T = g.KS * g.KS, Kp = T * g.Co / 2;
   Geom gp = g;
   gp.Co = g.Co / 2;
+  // stride 2, 3x3: the four parity classes as position classes of ONE product (igemm::ClassSched::s2) -- on this engine the four
+  // separate launches are ~40 us each whatever their size, so grouping pays on every grid (unlike the stride-1 classes)
+  if (g.stride == 2 && g.KS == 3 && g.pad == 1 && !avvad_tune().no_cls && !avvad_tune().no_s2_cls && avvad_tune().no_streamk == 0 && slab &&
+      g.N >= 128 && g.C >= 128 && (long)g.H * g.W * cdiv(g.N, 128) * cdiv(g.C, 128) <= cls_tile_cap()) {
+    const int MB = cdiv(g.N, 128), P = g.H * g.W;
+    igemm::ClassSched sc{g.H, g.W, cdiv(g.C, 128), g.Co / 64, MB, 3, 1, 1, 1, 1};
+    sc.s2 = 1; sc.Hq = g.Ho; sc.Wq = g.Wo;
+    const igemm::ClassRow cr{P, convop::div_magic(P)};
+    convop::Im2colDgradCls a{dy16, gp, g.N, cr, sc};
+    bgemm::RowPairsCls b{wd16, Kp, g.C, 9, 3, 1, cr, sc};
+    igemm::EpiCls e{dx, (long)P * g.C, nullptr, accumulate ? 1 : 0};
+    e.W = g.C; e.rows = g.N; e.cr = cr; e.sched = sc;
+    return bgemm::launch_cls<false>(a, b, e, MB * P * 128, g.C, s, slab);
+  }
   if (g.stride == 2) {
     if (!accumulate) hipLaunchKernelGGL(zero_f32, dim3(ew_grid((long)M * g.C)), dim3(256), 0, s, dx, (long)M * g.C);
     for (int ph = 0; ph < 2; ++ph)
