@@ -185,6 +185,157 @@ __global__ void __launch_bounds__(NW * 64, 2)
   }
 }
 
+// ---------------------------------------------------------------- the same kernel on the bf16 data path
+// x / dy are bf16 NHWC (128 bytes per pixel), the weights the K-contiguous bf16 packs [co][(tap, c)] / [c][(tap, co)] of the
+// bf16 engine (576 bf16 = 1152 bytes per row), y / dx fp32.  v_mfma_f32_32x32x16_bf16 takes 8 consecutive k per lane: lane
+// (i, h) fetches, per tap, the four 16-byte pieces "channels 16 s + 8 h .. + 7 of its pixel" (s = 0..3) and k-step (tap, s)
+// contracts them against the weight image's 16 bytes at k = tap * 64 + 16 s + 8 h of row co -- one ds_read_b128 each; the
+// image's rows are padded to 1168 bytes so that the 16 lanes of a read phase cover all 64 banks.  74 KB of LDS.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int W16_LD = 292;           // dwords per row of the bf16 weight image (288 + 4)
+
+template <bool FLIP>
+__global__ void __launch_bounds__(NW * 64, 2)
+    kernel16(const float* __restrict__ x16, const float* __restrict__ wpk16, float* __restrict__ y, const int M, const int H, const int W,
+             const unsigned mg_hw, const unsigned mg_w, const int accumulate, double* __restrict__ stat) {
+  __shared__ __attribute__((aligned(16))) float wl[64 * W16_LD + NW * 64 * 4];     // weights + the statistics exchange (doubles)
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const __amdgpu_buffer_rsrc_t rx = brsrc2g(x16);
+  const __amdgpu_buffer_rsrc_t ry = brsrc2g(y);
+  const long T = ((long)M + 31) / 32, G = gridDim.x;
+  const long t_lo = blockIdx.x * T / G, t_hi = (blockIdx.x + 1) * T / G;
+  const int HW = H * W;
+  const float* const bl = wl + li * W16_LD + lh * 4;            // this lane's weight row (+ 8 h in k)
+
+  int mbase = 0, rmask = 0, cmask = 0;
+  auto tile_ctx = [&](long tile) {
+    const int m = (int)tile * 32 + li;
+    const int n = mg_hw ? (int)__umulhi((unsigned)m, mg_hw) : m, r = m - n * HW;
+    const int h = mg_w ? (int)__umulhi((unsigned)r, mg_w) : r, w = r - h * W;
+    const bool in = m < M;
+    rmask = in ? ((h > 0 ? 1 : 0) | 2 | (h + 1 < H ? 4 : 0)) : 0;
+    cmask = (w > 0 ? 1 : 0) | 2 | (w + 1 < W ? 4 : 0);
+    mbase = m * 128 + lh * 16;
+  };
+  auto tap_off = [&](int tap) -> int {       // (tap: wave-uniform)
+    const int kh = (tap * 11) >> 5, kw = tap - kh * 3;
+    const int dh = FLIP ? 1 - kh : kh - 1, dw = FLIP ? 1 - kw : kw - 1;
+    const bool ok = ((rmask >> (dh + 1)) & 1) && ((cmask >> (dw + 1)) & 1);
+    return ok ? mbase + (dh * W + dw) * 128 : BUF_OOB;
+  };
+
+  double ds0 = 0, dq0 = 0, ds1 = 0, dq1 = 0;
+  f4v a0[4], a1[4];
+  f32x16 acc0, acc1;
+  auto contract = [&](const f4v (&av)[4], int tap) {      // one tap: 4 k-steps of 16, 8 MFMAs
+    const float* const bt = bl + tap * 32;
+    bf16x8 b[4][2];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      b[s][0] = *reinterpret_cast<const bf16x8*>(bt + s * 8);
+      b[s][1] = *reinterpret_cast<const bf16x8*>(bt + 32 * W16_LD + s * 8);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const bf16x8 a = __builtin_bit_cast(bf16x8, av[s]);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[s][0], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b[s][1], acc1, 0, 0, 0);
+    }
+  };
+  auto fetch = [&](f4v (&av)[4], int tap) {
+    const int vo = tap_off(tap);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) av[s] = bload4(rx, vo + s * 32, 0);
+  };
+  long tile = t_lo + wave;
+  if (tile < t_hi) {
+    tile_ctx(tile);
+    fetch(a0, 0);
+  }
+  {  // the weight image: 64 rows of 72 sixteen-byte pieces, padded rows
+    const float4* src = reinterpret_cast<const float4*>(wpk16);
+    for (int i = t; i < 64 * 72; i += NW * 64) {
+      const int row = i / 72, c4 = i - row * 72;
+      *reinterpret_cast<float4*>(wl + row * W16_LD + c4 * 4) = src[i];
+    }
+  }
+  __syncthreads();
+  for (; tile < t_hi; tile += NW) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int m0 = (int)tile * 32;
+#pragma unroll 1
+    for (int tp = 0; tp < 4; ++tp) {
+      fetch(a1, 2 * tp + 1);
+      contract(a0, 2 * tp);
+      fetch(a0, 2 * tp + 2);
+      contract(a1, 2 * tp + 1);
+    }
+    const bool more = tile + NW < t_hi;
+    if (more) {
+      tile_ctx(tile + NW);
+      fetch(a1, 0);
+    }
+    contract(a0, 8);
+    if (more) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a0[j] = a1[j];
+    }
+    if (stat != nullptr) {
+      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0 += acc0[r]; q0 = fmaf(acc0[r], acc0[r], q0);
+        s1 += acc1[r]; q1 = fmaf(acc1[r], acc1[r], q1);
+      }
+      ds0 += (double)s0; dq0 += (double)q0; ds1 += (double)s1; dq1 += (double)q1;
+    }
+    if (accumulate) {
+      float o0[16], o1[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mfma32_row(r, lh);
+        const int vo = m < M ? (m * 64 + li) * 4 : BUF_OOB;
+        o0[r] = bload(ry, vo, 0);
+        o1[r] = bload(ry, vo, 128);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mfma32_row(r, lh);
+        const int vo = m < M ? (m * 64 + li) * 4 : BUF_OOB;
+        bstore(o0[r] + acc0[r], ry, vo, 0);
+        bstore(o1[r] + acc1[r], ry, vo, 128);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = m0 + mfma32_row(r, lh);
+        const int vo = m < M ? (m * 64 + li) * 4 : BUF_OOB;
+        bstore(acc0[r], ry, vo, 0);
+        bstore(acc1[r], ry, vo, 128);
+      }
+    }
+  }
+  if (stat != nullptr) {
+    ds0 += __shfl_xor(ds0, 32, 64); dq0 += __shfl_xor(dq0, 32, 64);
+    ds1 += __shfl_xor(ds1, 32, 64); dq1 += __shfl_xor(dq1, 32, 64);
+    double* red = reinterpret_cast<double*>(wl + 64 * W16_LD);          // [NW][64][2]
+    if (lh == 0) {
+      red[(wave * 64 + li) * 2 + 0] = ds0; red[(wave * 64 + li) * 2 + 1] = dq0;
+      red[(wave * 64 + li + 32) * 2 + 0] = ds1; red[(wave * 64 + li + 32) * 2 + 1] = dq1;
+    }
+    __syncthreads();
+    if (t < 64) {
+      double sa = 0, sb = 0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { sa += red[(w * 64 + t) * 2 + 0]; sb += red[(w * 64 + t) * 2 + 1]; }
+      stat[((long)blockIdx.x * 2 + 0) * 64 + t] = sa;
+      stat[((long)blockIdx.x * 2 + 1) * 64 + t] = sb;
+    }
+  }
+}
+
 // ---------------------------------------------------------------- the weight gradient of the same convolutions
 // dW[(kh, kw, c)][co] = sum over pixels of x[n, h + kh - 1, w + kw - 1, c] . dy[n, h, w, co]: a 576 x 64 output contracted over
 // ~300 k pixels.  On the engine this is 4.5 row tiles of 128 (10 % of the last one's work multiplies nothing) cut 100 ways

@@ -620,6 +620,23 @@ static int conv64_launch(bool flip, const float* x, const float* wpk, float* y, 
   AVVAD_LAUNCH_CHECK();
   return AVVAD_OK;
 }
+// the same two products on the bf16 data path (bf16 activations / packs in, fp32 out): conv64::kernel16
+static inline bool conv64_16_ok(const Geom& g) {
+  const long M = (long)g.N * g.H * g.W;
+  return !avvad_tune().no_conv64 && g.C == 64 && g.Co == 64 && g.KS == 3 && g.stride == 1 && g.pad == 1 &&
+         g.Ho == g.H && g.Wo == g.W && M > 0 && fits_buf(M * 64) && (unsigned long)(M + 64) * (unsigned long)(g.H * g.W) < 0x100000000ull;
+}
+static int conv64_16_launch(bool flip, const float* x16, const float* wpk16, float* y, const Geom& g, int accumulate, hipStream_t s, double* stat) {
+  const int M = g.N * g.H * g.W;
+  const int grid = conv64::grid_for(M, conv64_cus());
+  const unsigned mg_hw = convop::div_magic((unsigned)(g.H * g.W)), mg_w = convop::div_magic((unsigned)g.W);
+  if (flip)
+    hipLaunchKernelGGL(conv64::kernel16<true>, dim3(grid), dim3(conv64::NW * 64), 0, s, x16, wpk16, y, M, g.H, g.W, mg_hw, mg_w, accumulate, stat);
+  else
+    hipLaunchKernelGGL(conv64::kernel16<false>, dim3(grid), dim3(conv64::NW * 64), 0, s, x16, wpk16, y, M, g.H, g.W, mg_hw, mg_w, accumulate, stat);
+  AVVAD_LAUNCH_CHECK();
+  return AVVAD_OK;
+}
 // number of partial-sum chunks the forward of convolution g leaves in its `stat` buffer (one per M tile of its GEMM)
 static inline int fwd_stat_chunks(const Geom& g, float* slab);
 
@@ -651,6 +668,7 @@ static int conv_fwd_t(const float* x, const float* wf, float* y, const Geom& g, 
 }
 static inline bool conv_fwd16_cls_ok(const Geom& g, float* slab);
 static inline int fwd_stat_chunks(const Geom& g, float* slab) {
+  if (avvad_tune().bf16 == 1 && conv64_16_ok(g)) return conv64::grid_for((long)g.N * g.H * g.W, conv64_cus());      // one chunk per workgroup
   if (avvad_tune().bf16 == 1)
     return (g.C % 64 == 0 && g.Co % 64 == 0 && conv_fwd16_cls_ok(g, slab)) ? g.Ho * g.Wo * cdiv(g.N, 128) : cdiv((long)g.N * g.Ho * g.Wo, 128);
   if (conv64_ok(g)) return conv64::grid_for((long)g.N * g.H * g.W, conv64_cus());      // one chunk per workgroup
@@ -814,6 +832,7 @@ static inline bool conv_dgrad16_cls_ok(const Geom& g, float* slab) {
 }
 static int conv_fwd16(const float* x16, const float* wf16, float* y, const Geom& g, hipStream_t s, float* slab, double* stat) {
   if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
+  if (conv64_16_ok(g)) return conv64_16_launch(false, x16, wf16, y, g, 0, s, stat);
   if (conv_fwd16_cls_ok(g, slab)) {
     const int MB = cdiv(g.N, 128), P = g.Ho * g.Wo;
     const int lsh = ((g.Ho - 1) * g.stride - g.pad + 2 > g.H - 1) ? 1 : 0, lsw = ((g.Wo - 1) * g.stride - g.pad + 2 > g.W - 1) ? 1 : 0;
@@ -839,6 +858,7 @@ static int conv_fwd16(const float* x16, const float* wf16, float* y, const Geom&
 }
 static int conv_dgrad16(const float* dy16, const float* wd16, float* dx, const Geom& g, int accumulate, hipStream_t s, float* slab) {
   if (!bf16_conv_ok(g)) return AVVAD_EINVAL;
+  if (conv64_16_ok(g)) return conv64_16_launch(true, dy16, wd16, dx, g, accumulate, s, nullptr);
   const int M = g.N * g.H * g.W, T = g.KS * g.KS, Kp = T * g.Co / 2;
   Geom gp = g;
   gp.Co = g.Co / 2;
