@@ -35,6 +35,7 @@ struct AvvadTune {
   int no_stem_kernel;       // 7x7 stem on the engine instead of the LDS-resident frame kernel
   int no_tall;              // 128x64 tiles instead of 256x64 for the 64-channel convolutions
   int wn_no_fused_tail;     // unfused encoder tail backward
+  int wn_no_tail_pair;      // fused encoder tail backward with one wave per time tile (4 waves / workgroup) instead of two
   int wn_no_fused_wgrad;    // unfused encoder block backward (dz, weight gradients as separate kernels)
   int no_fixup1;             // tuning aid: always the four-wave fix-up kernel
   int no_buf;                // convolution gathers with flat addressing + validity selects (the form operands >= 2 GiB use)

@@ -18,6 +18,7 @@ const OptName kOpts[] = {
     {"no_stem_kernel", "AVVAD_NO_STEM_KERNEL", &AvvadTune::no_stem_kernel},
     {"no_tall", "AVVAD_NO_TALL", &AvvadTune::no_tall},
     {"wn_no_fused_tail", "AVVAD_WN_NO_FUSED_TAIL", &AvvadTune::wn_no_fused_tail},
+    {"wn_no_tail_pair", "AVVAD_WN_NO_TAIL_PAIR", &AvvadTune::wn_no_tail_pair},
     {"wn_no_fused_wgrad", "AVVAD_WN_NO_FUSED_WGRAD", &AvvadTune::wn_no_fused_wgrad},
     {"wn_bwd_t", "AVVAD_WN_BWD_T", &AvvadTune::wn_bwd_t},
     {"no_buf", "AVVAD_NO_BUF", &AvvadTune::no_buf},

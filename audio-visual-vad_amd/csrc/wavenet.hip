@@ -1179,6 +1179,173 @@ __global__ void __launch_bounds__(256)
   for (int i = threadIdx.x; i < SLAB; i += 256) out[i] = red[i];
 }
 
+// The same pass with TWO waves per time tile (8 waves per workgroup, two per SIMD).  The kernel above keeps all Bn / 32 = 8
+// weight-gradient accumulators in one wave: 416 registers, one wave per SIMD, and its chain -- load, MFMA, LDS transpose, MFMA --
+// runs at a quarter of the matrix rate (310 us for 12.9 GFLOP at the bench shape).  Here waves 2p and 2p + 1 share tile after
+// tile: each takes HALF of the bottleneck rows (four 32-row tiles: z, dz, its four weight-gradient accumulators) and a partial
+// sum of d s over them; wave 2p + 1 hands its partial through LDS to wave 2p, which adds (fixed order) and stores.  Half the
+// registers per wave, twice the waves: the chains of two waves interleave on every SIMD.
+template <int NBT>   // Bn / 32 (even)
+__global__ void __launch_bounds__(512, 2)
+    tail_bwd_wgrad_pair(const float* __restrict__ s, const float* __restrict__ wb, const float* __restrict__ bb,
+                        const float* __restrict__ dout, float* __restrict__ dS, float* __restrict__ slab, int B, int Lv, int P) {
+  constexpr int Bn = NBT * 32, NH = NBT / 2;
+  constexpr int SLAB = Bn * 32 + Bn;
+  extern __shared__ float dyn[];
+  float* wl = dyn;                       // Bn x 33 padded weights
+  float* red = dyn + Bn * 33;            // SLAB partial sums of this workgroup
+  float* tiles = red + SLAB;             // 8 waves x 2 transpose tiles of 32 x 33
+  float* psum = tiles + 8 * 2 * 1056;    // 4 pairs x one 32 x 33 tile: the odd wave's partial d s
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int pair = wave >> 1, half = wave & 1;
+  const int tiles_per_seq = (Lv + 31) >> 5;
+  const long ntiles = (long)B * tiles_per_seq;
+  const long npairs = (long)gridDim.x * 4;
+  float* T0 = tiles + wave * 2 * 1056;   // s tile
+  float* T1 = T0 + 1056;                 // dz tile
+  float* PS = psum + pair * 1056;
+  for (int i = threadIdx.x; i < Bn * 32; i += 512) wl[(i >> 5) * 33 + (i & 31)] = wb[i];
+  for (int i = threadIdx.x; i < SLAB; i += 512) red[i] = 0.f;
+  __syncthreads();
+  f32x16 accW[NH];
+  float bsum[NH];
+#pragma unroll
+  for (int n = 0; n < NH; ++n) {
+    bsum[n] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accW[n][r] = 0.f;
+  }
+  const int rowV = Lv * 4;
+  const bool single = (Lv % P) == 0;
+  // every pair of the workgroup runs the same number of rounds (the barriers below are workgroup barriers)
+  const long rounds = (ntiles + npairs - 1) / npairs;
+  for (long rd_ = 0; rd_ < rounds; ++rd_) {
+    const long tile = rd_ * npairs + (long)blockIdx.x * 4 + pair;
+    const bool live = tile < ntiles;
+    const int b = __builtin_amdgcn_readfirstlane((int)((live ? tile : 0) / tiles_per_seq));
+    const int t = (int)((live ? tile : 0) - (long)b * tiles_per_seq) * 32 + li;
+    const bool ok = live && t < Lv;
+    const __amdgpu_buffer_rsrc_t rs = brsrc(s + (long)b * 32 * Lv, 32 * rowV);
+    const __amdgpu_buffer_rsrc_t rd = brsrc(dS + (long)b * 32 * Lv, 32 * rowV);
+    const __amdgpu_buffer_rsrc_t rg = brsrc(dout + (long)b * Bn * P, Bn * P * 4);
+    const int offs = ok ? t * 4 + lh * rowV : BUF_OOB;            // s row 2k + lh
+    const int offd = ok ? t * 4 + 4 * lh * rowV : BUF_OOB;        // dS row mfma32_row(r, lh)
+    float x[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) x[k] = bload(rs, offs, 2 * k * rowV);   // 0 past the sequence
+    __builtin_amdgcn_sched_barrier(0);
+    int pb[3];
+    float pc[3];
+    {
+      const int c0 = ok ? (int)(((long)t * P) / Lv) : 0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int p = c0 - 1 + j;
+        int a = 0, e = 0;
+        const bool in = ok && p >= 0 && p < P;
+        if (in) pool_bin(p, Lv, P, a, e);
+        const bool hit = in && t >= a && t < e;
+        pb[j] = hit ? p : 0;
+        pc[j] = hit ? 1.f / (float)(e - a) : 0.f;
+      }
+    }
+    int pbo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) pbo[j] = (pb[j] + 4 * lh * P) * 4;
+    float fs[16];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) T0[(2 * k + lh) * 33 + li] = x[k];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) fs[q] = T0[li * 33 + 2 * q + lh];
+    f32x16 accS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accS[r] = 0.f;
+#pragma unroll
+    for (int n = 0; n < NH; ++n) {
+      const int nb = (half * NH + n) * 32;
+      f32x16 accZ;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) accZ[r] = bb ? bb[nb + mfma32_row(r, lh)] : 0.f;
+      {
+        float wz[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wz[k] = wl[(nb + li) * 33 + 2 * k + lh];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) accZ = mfma32(wz[k], x[k], accZ);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // (phase by phase: hoisted, the next phases' operands spill)
+      float dz[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float g = 0.f;
+        if (single) {
+          g = bload(rg, pbo[1], (nb + mfma32_row(r, 0)) * P * 4) * pc[1];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 3; ++j) g = fmaf(bload(rg, pbo[j], (nb + mfma32_row(r, 0)) * P * 4), pc[j], g);
+        }
+        dz[r] = accZ[r] > 0.f ? g : 0.f;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      {
+        float wt[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) wt[k] = wl[(nb + mfma32_row(k, lh)) * 33 + li];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accS = mfma32(wt[r], dz[r], accS);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) T1[mfma32_row(r, lh) * 33 + li] = dz[r];
+      __builtin_amdgcn_wave_barrier();
+      float fz[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) { fz[q] = T1[li * 33 + 2 * q + lh]; bsum[n] += fz[q]; }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accW[n] = mfma32(fz[q], fs[q], accW[n]);
+    }
+    // d s = (rows of the first half) + (rows of the second half): the odd wave's partial crosses LDS, the even wave adds and stores
+    if (half == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) PS[mfma32_row(r, lh) * 33 + li] = accS[r];
+    }
+    __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bstore(accS[r] + PS[mfma32_row(r, lh) * 33 + li], rd, offd, mfma32_row(r, 0) * rowV);
+    }
+    __syncthreads();                     // (PS is free for the next round)
+  }
+  // the eight waves' sums meet in LDS in WAVE ORDER (plain adds between barriers)
+  for (int w = 0; w < 8; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int n = 0; n < NH; ++n) {
+        const int nt = half * NH + n;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(nt * 32 + mfma32_row(r, lh)) * 32 + li] += accW[n][r];
+      }
+      if (lh == 0) {
+#pragma unroll
+        for (int n = 0; n < NH; ++n) red[Bn * 32 + (half * NH + n) * 32 + li] += bsum[n];
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lh == 1) {
+#pragma unroll
+        for (int n = 0; n < NH; ++n) red[Bn * 32 + (half * NH + n) * 32 + li] += bsum[n];
+      }
+    }
+  }
+  __syncthreads();
+  float* out = slab + (long)blockIdx.x * SLAB;
+  for (int i = threadIdx.x; i < SLAB; i += 512) out[i] = red[i];
+}
+
 // dW_b[bn][c] += sum_blocks slab[bn*32 + c]; db[bn] += slab[Bn*32 + bn]   -- fixed order: 32 elements x 8 slab groups per
 // workgroup, ascending slabs inside a group, the groups combined in LDS in order (no atomics, see wn_wgrad_reduce_all)
 __global__ void __launch_bounds__(256)
@@ -2015,6 +2182,18 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     // d s_N and the bottleneck's weight + bias gradients in one pass; dz_t is never materialised
     long blocks = ((long)B * cdiv(Lv, 32) + 3) / 4;
     if (blocks > 256) blocks = 256;        // 1 workgroup / CU is resident: one round
+    if (!avvad_tune().wn_no_tail_pair) {
+      // two waves per time tile, 8 waves per workgroup (tail_bwd_wgrad_pair)
+      const size_t lds = ((size_t)Bn * 33 + (size_t)Bn * 33 + 16 * 1056 + 4 * 1056) * sizeof(float);
+      static bool attr_set2 = false;
+      if (!attr_set2) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(tail_bwd_wgrad_pair<8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) return AVVAD_ELAUNCH;
+        attr_set2 = true;
+      }
+      hipLaunchKernelGGL(tail_bwd_wgrad_pair<8>, dim3((int)blocks), dim3(512), lds, s, ws + p.s[p.n], prm->bott_w,
+                         d->use_bias ? prm->bott_b : (const float*)nullptr, dout, GA, ws + p.slab, B, Lv, d->P);
+    } else {
     const size_t lds = ((size_t)Bn * 33 + (size_t)Bn * 33 + 8 * 1056) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
@@ -2024,6 +2203,7 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
     }
     hipLaunchKernelGGL(tail_bwd_wgrad_mfma<8>, dim3((int)blocks), dim3(256), lds, s, ws + p.s[p.n], prm->bott_w,
                        d->use_bias ? prm->bott_b : (const float*)nullptr, dout, GA, ws + p.slab, B, Lv, d->P);
+    }
     hipLaunchKernelGGL(tail_wgrad_reduce, dim3(cdiv(Bn * 33, 32)), dim3(256), 0, s, ws + p.slab, (int)blocks, Bn, g->bott_w,
                        d->use_bias ? g->bott_b : (float*)nullptr);
   } else if (tail_mfma) {
