@@ -2300,10 +2300,11 @@ extern "C" int avvad_wavenet_bwd(const float* wave, const avvad_wavenet_params* 
         }
       }
       blocks = ((long)B * cdiv(Li, 32) + 3) / 4;
-      // Beside the trunk's backward on another stream (shared_device) the high-occupancy dx kernel costs the STEP 0.16 ms
-      // although it is 15 % faster alone: 1024 workgroups of it displace the convolutions' persistent workers more
-      // often.  Option wn_dx: 1 forces the resident-weights kernel, 2 the high-occupancy one.
-      const bool dx_occ = avvad_tune().wn_dx == 2 || (avvad_tune().wn_dx == 0 && !d->shared_device);
+      // The high-occupancy dx kernel everywhere.  (Round 2 measured it 0.16 ms/step SLOWER beside the trunk's backward on another
+      // stream, and the shared_device hint picked the resident-weights form there; with this round's trunk kernels -- layer 1 off
+      // the persistent engine, fewer and longer class launches -- the same A/B reads 0.06 ms FASTER: bench.py --ab wn_dx=1.)
+      // Option wn_dx: 1 forces the resident-weights kernel, 2 the high-occupancy one.
+      const bool dx_occ = avvad_tune().wn_dx == 2 || avvad_tune().wn_dx == 0;
       if (buf_ok(B, Li) && avvad_tune().wn_flat != 1 && dx_occ) {
         if (blocks > 1024) blocks = 1024;                 // 4 waves per SIMD resident
         if (blocks >= 8) blocks = (blocks + 7) / 8 * 8;
