@@ -520,6 +520,13 @@ def main():
             if world == 1 and kind == "av":     # CPU baseline and CPU-reference delta: rank 0 at N=1 only
                 # (bf16: the delta of the bf16 arithmetic to the fp32 CPU reference, BASELINE configs[4]'s own tolerance applies)
                 out["cpu_ref_max_abs_delta"], out["cpu_ref_max_abs"] = parity_probe(torch, model)
+                # the same probe at the INITIAL weights (what the parity tests bound: 1e-4 fp32, 3e-2 of max|ref| bf16); the
+                # line above is taken at the weights the timed steps left behind -- saturated logits of a model that has
+                # memorised its one batch, where a rounding difference is amplified the most
+                torch.manual_seed(0)
+                fresh = DeepVAD_AV(2, 1024, 1, use_mcb=False, eps=1e-8, wavenet_params=w0(T)).to(dev).train()
+                out["cpu_ref_init_max_abs_delta"], out["cpu_ref_init_max_abs"] = parity_probe(torch, fresh)
+                del fresh
                 log("parity probe done")
                 out["cpu_baseline"] = cpu_baseline(torch)
                 log("cpu baseline done")
