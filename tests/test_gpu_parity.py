@@ -199,7 +199,7 @@ def test_backward_only_cu_reservation(lib_options):
 @pytest.mark.parametrize("name,alt", [("wn_tiny", 0), ("wn_fw3_qc2", 0), ("wn_nobias", 0), ("wn_w0", 0), ("wn_w0_t16", 0),
                                       ("wn_nobias", 1), ("wn_w0", 1), ("wn_w0_t16", 1), ("wn_w0", 2), ("wn_w0_t16", 2),
                                       ("wn_nobias", 3), ("wn_w0", 3), ("wn_nobias", 4), ("wn_w0", 4), ("wn_w0_t16", 4),
-                                      ("wn_w0_t16", 5), ("wn_fw3_qc2", 5)])
+                                      ("wn_w0_t16", 5), ("wn_fw3_qc2", 5), ("wn_w0", 6), ("wn_w0_t16", 6)])
 def test_wavenet_golden(name, alt, lib_options):
     """alt=1: the alternate block backward kept in the library (transposed products, no LDS transposes); alt=2: the kernel
     forms picked beside another stream (dx with resident weights, forward with resident weights + cross-tile prefetch);
@@ -220,6 +220,8 @@ def test_wavenet_golden(name, alt, lib_options):
         # change; shapes that go through the GEMM engine (fw = 3, qc = 2: the Conv1d weight gradients) multiply bf16-rounded
         # operands there.  Stated tolerance for those gradients: relative L2 <= 1e-2 (2^-8 per operand, random signs).
         lib_options("bf16", 1)
+    elif alt == 6:
+        lib_options("wn_no_tail_pair", 1)   # the fused tail backward with one wave per time tile (the default pairs two waves)
     g = load_golden(name)
     cfg = wn_cfg_from(g)
     m = wavenet_autoencoder(**cfg)
